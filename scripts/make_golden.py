@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the importable subset of the reference.
+
+Run in the build container only (needs /root/reference, which never travels):
+    python scripts/make_golden.py
+The six importable reference files are imported as-is; their
+outputs on seeded inputs are stored together with the inputs.  The fixtures are
+data (inputs + expected outputs), never reference source.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, REF)
+    import my_pixelwise_xentropy as RX
+    import branchy_seg_losses as RBSL
+    import compute_mIoU as RM
+    from scipy.stats import entropy
+
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---- losses: several seeded cases incl. the SURVEY section 4 probe ------
+    cases = [  # (seed, E, B, C, H, W, void_label)
+        (0, 3, 2, 21, 9, 7, 21),
+        (1, 2, 3, 19, 17, 13, 19),
+        (2, 4, 2, 5, 33, 20, 5),
+        (3, 2, 2, 21, 24, 31, 21),
+    ]
+    for seed, E, B, C, H, W, void in cases:
+        torch.manual_seed(seed)
+        y = torch.randn(E, B, C, H, W)
+        t = torch.randint(0, C + 1, [B, 1, H, W])
+        out = {"y": y.numpy(), "t": t.numpy(), "void": void}
+        for red in ("sum", "mean"):
+            yy = y.clone().requires_grad_(True)
+            l = RX.BrXEntropyLoss(ignore_index=void, b_reduction=red, n_exits=E)(yy, t)
+            l.mean().backward()
+            out[f"ce_{red}"] = l.detach().numpy()
+            out[f"ce_{red}_grad"] = yy.grad.numpy()
+        for prev in (False, True):
+            yy = y.clone().requires_grad_(True)
+            l = RBSL.LovaszSoftmax(classes="present", ignore=void, n_branches=E - 1,
+                                   prev_out=prev)(yy, t)
+            l.mean().backward()
+            out[f"lovasz_prev{int(prev)}"] = l.detach().numpy()
+            out[f"lovasz_prev{int(prev)}_grad"] = yy.grad.numpy()
+        # per-exit mIoU through the reference accumulator
+        mi = []
+        for e in range(E):
+            m = RM.mIoU(C)
+            m(y[e], t)
+            mi.append(m.compute().item())
+            if e == 0:
+                out["acc0"] = m.accumulator.numpy().copy()
+        out["miou"] = np.array(mi, dtype=np.float64)
+        # entropy gate (eval_br_ent.py:29: scipy entropy base C over axis 0, then mean)
+        ents = []
+        for e in range(E):
+            for b in range(B):
+                p = torch.softmax(y[e, b:b + 1] * 3.0, 1).squeeze(0).numpy()
+                ents.append(np.mean(entropy(p, base=C, axis=0)))
+        out["gate_scale"] = 3.0
+        out["entropy"] = np.array(ents, dtype=np.float64).reshape(E, B)
+        np.savez_compressed(os.path.join(OUT, f"losses_seed{seed}.npz"), **out)
+        print(f"seed {seed}: ce_sum={out['ce_sum']:.9f} lovasz={out['lovasz_prev0']:.9f} "
+              f"miou0={mi[0]:.9f}")
+
+    # ---- the reference's own self-check tensors (compute_mIoU.py:66-141) ----
+    y_true = np.array([[[[0, 1, 1, 1, 0, 0], [1, 1, 2, 2, 1, 1], [1, 1, 2, 2, 1, 1], [0, 1, 1, 1, 0, 0]]],
+                       [[[0, 3, 3, 3, 2, 0], [0, 3, 2, 2, 3, 1], [0, 3, 2, 2, 3, 1], [0, 3, 3, 3, 3, 0]]]],
+                      dtype=np.float32)
+    y_pred = 100 * np.array([
+        [[[1, 0, 0, 0, 1, 1], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 1, 1]],
+         [[0, 1, 1, 1, 0, 0], [1, 1, 0, 0, 1, 1], [1, 1, 0, 0, 1, 1], [0, 1, 1, 1, 0, 0]],
+         [[0, 0, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 0, 0]],
+         [[0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0]]],
+        [[[1, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 1]],
+         [[0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0]],
+         [[0, 0, 0, 0, .5, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 0, 0]],
+         [[0, 1, 1, 1, 1.5, 1], [0, 1, 0, 0, 1, 0], [0, 1, 0, 0, 1, 0], [0, 1, 1, 1, 1, 0]]]],
+        dtype=np.float32)
+    m = RM.mIoU(n_classes=4)
+    m(torch.from_numpy(y_pred), torch.from_numpy(y_true))
+    val = m.compute().item()
+    assert abs(val - 0.9513888955116272) < 1e-12, val
+    np.savez_compressed(os.path.join(OUT, "miou_selfcheck.npz"), y_pred=y_pred, y_true=y_true,
+                        miou=np.float64(val), acc=m.accumulator.numpy())
+    print("selfcheck mIoU", val)
+
+
+if __name__ == "__main__":
+    main()
