@@ -1,0 +1,96 @@
+"""ctypes binding of libeeseg.so (the C ABI declared in include/eeseg.h).
+
+The HIP library is the product: if it is missing or fails to load this module
+raises - there is no CPU/PyTorch fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeeseg.so")
+
+F32, BF16 = 0, 1
+
+
+class EesegError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
+                ("stats", C.c_void_p)] + \
+               [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
+                                       "smul", "off_h", "off_w", "tstep_h", "tstep_w", "sdiv",
+                                       "ldy", "ldres", "relu", "dtype")]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)] + \
+               [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
+                                       "stride", "pad", "dil", "dtype", "accumulate")]
+
+
+_vp, _i, _i64, _f, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol include/eeseg.h declares
+SIGNATURES = {
+    "eeseg_last_error": (C.c_char_p, []),
+    "eeseg_version": (_i, []),
+    "eeseg_conv_stats_tiles": (_i, [_i, _i, _i]),
+    "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
+    "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),
+    "eeseg_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_pack_matrix": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "eeseg_im2col_nchw": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
+    "eeseg_colreduce_workspace": (_i64, [_i64, _i]),
+    "eeseg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp]),
+    "eeseg_bn_finalize": (_i, [_vp, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    "eeseg_bn_eval_scale_shift": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp]),
+    "eeseg_bn_apply": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "eeseg_channel_stats": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _i64, _vp]),
+    "eeseg_bn_bwd_reduce": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
+    "eeseg_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i, _vp, _i, _i64, _i, _i,
+                                _i, _vp]),
+    "eeseg_scale_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "eeseg_maxpool3x3s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_sum_hw": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _i, _vp]),
+    "eeseg_broadcast_hw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "eeseg_dropout": (_i, [_vp, _vp, _i64, _f, _u64, _i, _vp]),
+    "eeseg_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "eeseg_add_inplace": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "eeseg_colsum": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _i64, _vp]),
+    "eeseg_upsample_bilinear_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_upsample_bilinear_nchw_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_upsample_ce_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp, _vp]),
+    "eeseg_upsample_ce_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp, _f, _vp, _vp]),
+    "eeseg_argmax_confusion": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
+    "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),
+    "eeseg_sgd_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises EesegError when libeeseg.so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EesegError(
+                f"{LIB_PATH} not found: the HIP extension is the product and there is no fallback. "
+                "Build it with `python -m ee_semantic_segmentation_amd.build`.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EesegError(f"{what} failed ({rc}): {lib().eeseg_last_error().decode()}")

@@ -1,0 +1,399 @@
+// Implicit-GEMM convolution for gfx950 (forward and data-gradient).
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (tap, cin).
+//   A operand = weight tile (rows = cout), B operand = gathered pixel tile, so the
+//   accumulator holds 4 consecutive couts per lane/register group -> the epilogue
+//   writes whole NHWC rows.
+// Tile: 128 pixels x BN couts x 128 bytes of K (64 bf16 / 32 f32 channels of one
+//   tap) per step; 256 threads = 4 waves; each wave owns 32x32 MFMA tiles
+//   (v_mfma_f32_32x32x16_bf16 or the exact-fp32 v_mfma_f32_32x32x2_f32).
+// Staging: global -> registers (buffer_load, out-of-image taps read as zero via
+//   an out-of-range offset) -> XOR-swizzled LDS, double buffered, one barrier per
+//   K step; taps that no pixel of the tile can see (dilation 12/24/36 on 65x65
+//   maps) are skipped entirely.
+// Epilogue: acc*scale+shift -> LDS (row major) -> per-channel partial sums for
+//   train-mode BatchNorm + coalesced 16-byte row stores (+residual, ReLU).
+#include "eeseg_common.h"
+
+namespace {
+
+struct ConvP {
+    const void* x; const void* w; void* y;
+    const float* scale; const float* shift; const void* residual; float* stats;
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
+    int smul, off_h, off_w, tstep_h, tstep_w, sdiv;
+    int ldy, ldres, relu;
+    int M, HWout, n_tiles, m_tiles;
+    uint32_t xbytes, wbytes;
+    int vec_ok;   // 1: 16-byte row stores allowed (alignment / Cout multiple)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ bool map_coord(int base, int t, int tstep, int sdiv, int lim, int& out) {
+    int v = base + t * tstep;
+    if (sdiv > 1) {
+        if (v < 0) return false;
+        const int q = v / sdiv;
+        if (q * sdiv != v) return false;
+        v = q;
+    }
+    out = v;
+    return (unsigned)v < (unsigned)lim;
+}
+
+constexpr int BM = 128;     // pixels per tile
+constexpr int ROWB = 128;   // bytes of K per LDS row
+
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
+    constexpr int EPK = ROWB / (int)sizeof(T);        // K elements per step
+    constexpr int WAVES_C = BN / 64;                  // waves along cout
+    constexpr int WAVES_P = 4 / WAVES_C;              // waves along pixels
+    constexpr int TI = 2;                             // 32-wide cout tiles per wave
+    constexpr int TJ = BM / (32 * WAVES_P);           // 32-wide pixel tiles per wave
+    constexpr int WCH = BN / 32;                      // weight chunks per thread
+    constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk
+    constexpr int CPR = BN / EPC;                     // chunks per output row
+    constexpr int SROW = BN * (int)sizeof(T) + 16;    // staged output row bytes
+    constexpr int MAIN_BYTES = 2 * (BM + BN) * ROWB;
+    constexpr int EPI_BYTES = BM * SROW + 4 * BN * 2 * 4;
+    constexpr int LDS_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + 16;
+    typedef typename Mma<T>::Frag Frag;
+
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    char* sX = smem;                         // [2][BM][ROWB]
+    char* sW = smem + 2 * BM * ROWB;         // [2][BN][ROWB]
+    unsigned* sMask = reinterpret_cast<unsigned*>(smem + LDS_BYTES - 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int taps = p.R * p.S;
+
+    // ---- per-thread gather rows (fixed for the whole K loop) -----------------
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    int hb[4], wb[4], nb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        if (m < p.M) {
+            const int n = m / p.HWout;
+            const int rem = m - n * p.HWout;
+            const int ho = rem / p.Wout;
+            const int wo = rem - ho * p.Wout;
+            hb[j] = ho * p.smul + p.off_h;
+            wb[j] = wo * p.smul + p.off_w;
+            nb[j] = n * p.Hin * p.Win;
+        } else {
+            hb[j] = -(1 << 28); wb[j] = -(1 << 28); nb[j] = 0;
+        }
+    }
+    // ---- which taps can any pixel of this tile see? ---------------------------
+    if (tid == 0) *sMask = 0u;
+    __syncthreads();
+    {
+        unsigned mine = 0u;
+        for (int t = 0; t < taps; ++t) {
+            const int r = t / p.S, s = t - r * p.S;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int hi, wi;
+                any |= map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) &&
+                       map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi);
+            }
+            if (any) mine |= 1u << t;
+        }
+        // OR-reduce inside the wave, then one LDS atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
+        if (lane == 0 && mine) atomicOr(sMask, mine);
+    }
+    __syncthreads();
+    const unsigned tapmask = *sMask;
+    const int kc_steps = p.Cin / EPK;
+    const int nk = __popc(tapmask) * kc_steps;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    i32x4 ra[4], rwv[WCH];
+    int tap = -1, c0 = 0;
+    unsigned rest = tapmask;
+
+    auto next_tile = [&]() {   // block-uniform iterator over (valid tap, channel step)
+        if (tap < 0 || c0 + EPK >= p.Cin) {
+            tap = __ffs(rest) - 1;
+            rest &= rest - 1;
+            c0 = 0;
+        } else {
+            c0 += EPK;
+        }
+    };
+    auto load_tile = [&]() {
+        const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int hi = 0, wi = 0;
+            const bool ok = map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) &&
+                            map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi);
+            const uint32_t off = ok ? (uint32_t)(((nb[j] + hi * p.Win + wi) * p.Cin + c0) * (int)sizeof(T) + lchunk * 16)
+                                    : EESEG_OOB;
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            const int co = n0 + lrow + 32 * j;
+            const uint32_t off = (co < p.Cout)
+                                     ? (uint32_t)(((co * taps + tap) * p.Cin + c0) * (int)sizeof(T) + lchunk * 16)
+                                     : EESEG_OOB;
+            rwv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = lrow + 32 * j;
+            *reinterpret_cast<i32x4*>(sX + buf * BM * ROWB + row * ROWB + ((lchunk ^ ((row >> 1) & 7)) << 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+            const int row = lrow + 32 * j;
+            *reinterpret_cast<i32x4*>(sW + buf * BN * ROWB + row * ROWB + ((lchunk ^ ((row >> 1) & 7)) << 4)) = rwv[j];
+        }
+    };
+
+    const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+
+    if (nk > 0) {
+        next_tile();
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
+            next_tile();
+            load_tile();
+        }
+        const char* xa = sX + cur * BM * ROWB + (wp * 32 * TJ + fr) * ROWB;
+        const char* wa = sW + cur * BN * ROWB + (wc * 64 + fr) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((ks * 2 + fh) ^ fsw) << 4;
+            Frag wf[TI], xf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) wf[i] = *reinterpret_cast<const Frag*>(wa + i * 32 * ROWB + coff);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) xf[j] = *reinterpret_cast<const Frag*>(xa + j * 32 * ROWB + coff);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue 1: acc -> (scale, shift) -> LDS staging [pixel][cout] --------
+    // (the trailing __syncthreads of the K loop / prologue guarantees nobody still reads sX/sW)
+    char* stage = smem;
+    float* sRed = reinterpret_cast<float*>(smem + BM * SROW);   // [4 waves][2][BN]
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wc * 64 + i * 32 + 8 * g + 4 * fh;   // local cout of element 0
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = n0 + cl + e;
+                if (co < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[co];
+                    if (p.shift) sh[e] = p.shift[co];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int px = wp * 32 * TJ + j * 32 + fr;
+                T v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][j][4 * g + e] * sc[e] + sh[e]);
+                T* dst = reinterpret_cast<T*>(stage + px * SROW) + cl;
+                if constexpr (sizeof(T) == 2) {
+                    *reinterpret_cast<bf16x4*>(dst) = bf16x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: row-major read back, residual/ReLU, stats, coalesced stores ----
+    const int c = tid % CPR, r0 = tid / CPR;
+    constexpr int RSTEP = 256 / CPR;
+    const int cg = n0 + c * EPC;                         // first global cout of my chunk
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* yout = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const bool full = p.vec_ok && (cg + EPC <= p.Cout);
+    for (int row = r0; row < BM; row += RSTEP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        union { i32x4 q; T e[EPC]; } u;
+        u.q = *reinterpret_cast<const i32x4*>(stage + row * SROW + c * 16);
+        T* v = u.e;
+        if (res != nullptr || p.relu) {
+            if (res != nullptr) {
+                if (full) {
+                    union { i32x4 q; T e[EPC]; } ur;
+                    ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+                    const T* rv = ur.e;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(rv[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
+            }
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float f = to_f32(v[e]);
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+        if (full) {
+            *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
+        }
+    }
+    if (p.stats) {
+        // lanes holding the same chunk index: lane, lane^CPR, lane^2CPR, ...
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o);
+                s2[e] += __shfl_xor(s2[e], o);
+            }
+        }
+        if constexpr (CPR <= 64) {
+            if (lane < CPR) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    sRed[(wave * 2 + 0) * BN + lane * EPC + e] = s1[e];
+                    sRed[(wave * 2 + 1) * BN + lane * EPC + e] = s2[e];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid - which * BN;
+            // waves that share a chunk column set: with CPR<=64 every wave covers all chunks
+            float t = sRed[(0 * 2 + which) * BN + col] + sRed[(1 * 2 + which) * BN + col] +
+                      sRed[(2 * 2 + which) * BN + col] + sRed[(3 * 2 + which) * BN + col];
+            if (n0 + col < p.Cout) p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = t;
+        }
+    }
+}
+
+template <typename T, int BN>
+int launch(const ConvP& p, hipStream_t st) {
+    const int grid = p.m_tiles * p.n_tiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3(grid), dim3(256), 0, st, p);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+}  // namespace
+
+extern "C" int eeseg_conv_stats_tiles(int N, int Hout, int Wout) {
+    const long long M = (long long)N * Hout * Wout;
+    return (int)((M + BM - 1) / BM);
+}
+
+extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
+    EESEG_CHECK(a && a->x && a->w && a->y, EESEG_ERR_ARG, "conv_igemm: null pointer");
+    const int es = eeseg_dtype_size(a->dtype);
+    EESEG_CHECK(es != 0, EESEG_ERR_ARG, "conv_igemm: bad dtype %d", a->dtype);
+    const int epk = 128 / es;
+    EESEG_CHECK(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0 && a->Cout > 0, EESEG_ERR_ARG,
+                "conv_igemm: non-positive shape");
+    EESEG_CHECK(a->Cin > 0 && a->Cin % epk == 0, EESEG_ERR_ARG, "conv_igemm: Cin=%d must be a multiple of %d",
+                a->Cin, epk);
+    EESEG_CHECK(a->R >= 1 && a->S >= 1 && a->R * a->S <= 32, EESEG_ERR_ARG, "conv_igemm: R*S=%d unsupported",
+                a->R * a->S);
+    EESEG_CHECK(a->sdiv >= 1 && a->smul >= 1, EESEG_ERR_ARG, "conv_igemm: bad stride mapping");
+    EESEG_CHECK(a->ldy >= a->Cout, EESEG_ERR_ARG, "conv_igemm: ldy < Cout");
+    EESEG_CHECK(!a->residual || a->ldres >= a->Cout, EESEG_ERR_ARG, "conv_igemm: ldres < Cout");
+    const long long M = (long long)a->N * a->Hout * a->Wout;
+    const long long xbytes = (long long)a->N * a->Hin * a->Win * a->Cin * es;
+    const long long wbytes = (long long)a->Cout * a->R * a->S * a->Cin * es;
+    EESEG_CHECK(xbytes < (1ll << 31) && wbytes < (1ll << 31) && M < (1ll << 31) - 256, EESEG_ERR_TOO_LARGE,
+                "conv_igemm: tensor exceeds 2 GiB descriptor range (x=%lld w=%lld bytes)", xbytes, wbytes);
+    EESEG_CHECK(((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->w & 15) == 0, EESEG_ERR_ARG,
+                "conv_igemm: x/w must be 16-byte aligned");
+
+    ConvP p;
+    p.x = a->x; p.w = a->w; p.y = a->y;
+    p.scale = a->scale; p.shift = a->shift; p.residual = a->residual; p.stats = a->stats;
+    p.N = a->N; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin;
+    p.Hout = a->Hout; p.Wout = a->Wout; p.Cout = a->Cout; p.R = a->R; p.S = a->S;
+    p.smul = a->smul; p.off_h = a->off_h; p.off_w = a->off_w;
+    p.tstep_h = a->tstep_h; p.tstep_w = a->tstep_w; p.sdiv = a->sdiv;
+    p.ldy = a->ldy; p.ldres = a->ldres; p.relu = a->relu;
+    p.M = (int)M; p.HWout = a->Hout * a->Wout;
+    p.m_tiles = (int)((M + BM - 1) / BM);
+    p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
+    const int epc = 16 / es;
+    p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
+               (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    const bool narrow = a->Cout <= 64;
+    p.n_tiles = narrow ? (a->Cout + 63) / 64 : (a->Cout + 127) / 128;
+    if (a->dtype == EESEG_BF16) return narrow ? launch<bf16_t, 64>(p, st) : launch<bf16_t, 128>(p, st);
+    return narrow ? launch<float, 64>(p, st) : launch<float, 128>(p, st);
+}

@@ -1,0 +1,258 @@
+// Convolution weight gradient for gfx950.
+//
+// GEMM view per filter tap: dW[cout][cin] += sum_pixels dY[pixel][cout] * X[pixel'][cin]
+//   (pixel' = tap-shifted input pixel).  K = pixels is the SLOW dimension of both
+//   operands in NHWC memory, so the bf16 path feeds the MFMA through the gfx950
+//   transposing LDS read (ds_read_b64_tr_b16); the fp32 path (v_mfma_f32_32x32x2_f32
+//   takes one k per lane) reads plain dwords.
+// Tile: 128 couts x 128 cins x (64 bf16 / 32 f32) pixels per step, 4 waves of
+//   64x64; split-K over pixel ranges, fp32 atomics into dW (KRSC, fp32).
+#include "eeseg_common.h"
+
+namespace {
+
+struct WgP {
+    const void* x; const void* dy; float* dw;
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad, dil;
+    int lddy;
+    int M, HWout, co_tiles, ci_tiles, splits, chunk;
+    uint32_t xbytes, dybytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int KP = 128 / ES;            // pixels per K step (64 / 32)
+    constexpr int ROWW = 128 * ES;          // bytes per LDS row = 128 channels
+    constexpr int CPRW = ROWW / 16;         // 16-byte chunks per row (16 / 32)
+    constexpr int RPP = 256 / CPRW;         // rows per load pass (16 / 8)
+    constexpr int EPC = 16 / ES;
+    constexpr int TILE = KP * ROWW;         // 16 KiB
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
+    char* sDY = smem;                       // [2][KP][ROWW]
+    char* sX = smem + 2 * TILE;             // [2][KP][ROWW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = p.R * p.S;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+    const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+    const int tap = bid % taps;
+    const int split = bid / taps;
+    const int co0 = co_t * 128, ci0 = ci_t * 128;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int dh = tr * p.dil - p.pad, dwv = ts * p.dil - p.pad;
+
+    const int ps = split * p.chunk;
+    const int pe = min(p.M, ps + p.chunk);
+    const int nk = (pe > ps) ? (pe - ps + KP - 1) / KP : 0;
+
+    const int c = tid % CPRW, rbase = tid / CPRW;
+    // running pixel coordinates of my 4 rows
+    int pn[4], ph[4], pw[4], pm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = ps + rbase + j * RPP;
+        pm[j] = m;
+        const int n = m / p.HWout;
+        const int rem = m - n * p.HWout;
+        ph[j] = rem / p.Wout;
+        pw[j] = rem - ph[j] * p.Wout;
+        pn[j] = n;
+    }
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+    const bool co_ok = (co0 + c * EPC) < p.Cout;
+    const bool ci_ok = (ci0 + c * EPC) < p.Cin;
+
+    i32x4 rdyv[4], rxv[4];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = pm[j] < pe;
+            const uint32_t offd = (in && co_ok) ? (uint32_t)((pm[j] * p.lddy + co0) * ES + c * 16) : EESEG_OOB;
+            rdyv[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)offd, 0, 0);
+            const int hi = ph[j] * p.stride + dh, wi = pw[j] * p.stride + dwv;
+            const bool ok = in && ci_ok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            const uint32_t offx = ok ? (uint32_t)((((pn[j] * p.Hin + hi) * p.Win + wi) * p.Cin + ci0) * ES + c * 16)
+                                     : EESEG_OOB;
+            rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)offx, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pm[j] += KP;
+            pw[j] += KP;
+            while (pw[j] >= p.Wout) { pw[j] -= p.Wout; ph[j] += 1; }
+            while (ph[j] >= p.Hout) { ph[j] -= p.Hout; pn[j] += 1; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = rbase + j * RPP;
+            const int o = row * ROWW + ((c * 16) ^ ((row & 3) << 6));
+            *reinterpret_cast<i32x4*>(sDY + buf * TILE + o) = rdyv[j];
+            *reinterpret_cast<i32x4*>(sX + buf * TILE + o) = rxv[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wr = wave >> 1, wcI = wave & 1;     // cout half, cin half
+    if (nk > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
+            advance();
+            load_tile();
+        }
+        const char* a = sDY + cur * TILE;
+        const char* b = sX + cur * TILE;
+        if constexpr (ES == 2) {
+            // transposing reads: lane l of each 16-lane group addresses row q=(l>>2)&3, 4 channels at 4*(l&3)
+            const int q = (lane >> 2) & 3;
+            const int chl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int sw = q << 6;
+#pragma unroll
+            for (int ks = 0; ks < KP / 16; ++ks) {
+                bf16x8 af[2], bfr[2];
+                const int row0 = ks * 16 + 8 * (lane >> 5) + q;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int cb = ((wr * 64 + i * 32 + chl) * 2) ^ sw;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a + row0 * ROWW + cb));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a + (row0 + 4) * ROWW + cb));
+                    union { s16x4 h[2]; bf16x8 v; } u;
+                    u.h[0] = lo; u.h[1] = hi;
+                    af[i] = u.v;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cb = ((wcI * 64 + j * 32 + chl) * 2) ^ sw;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(b + row0 * ROWW + cb));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(b + (row0 + 4) * ROWW + cb));
+                    union { s16x4 h[2]; bf16x8 v; } u;
+                    u.h[0] = lo; u.h[1] = hi;
+                    bfr[j] = u.v;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll 4
+            for (int kk = 0; kk < KP / 2; ++kk) {
+                const int row = 2 * kk + fh;
+                const int sw = (row & 3) << 6;
+                float av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    av[i] = *reinterpret_cast<const float*>(a + row * ROWW + (((wr * 64 + i * 32 + fr) * 4) ^ sw));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bv[j] = *reinterpret_cast<const float*>(b + row * ROWW + (((wcI * 64 + j * 32 + fr) * 4) ^ sw));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (has_next) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: fp32 atomics into dW[co][tap][ci] ---------------------------
+    if (nk == 0) return;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wcI * 64 + j * 32 + fr;
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                if (co < p.Cout) {
+                    float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
+                    __builtin_amdgcn_global_atomic_fadd_f32(
+                        (__attribute__((address_space(1))) float*)dst, acc[i][j][e]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
+    EESEG_CHECK(a && a->x && a->dy && a->dw, EESEG_ERR_ARG, "conv_wgrad: null pointer");
+    const int es = eeseg_dtype_size(a->dtype);
+    EESEG_CHECK(es != 0, EESEG_ERR_ARG, "conv_wgrad: bad dtype");
+    const int epc = 16 / es;
+    EESEG_CHECK(a->Cin % epc == 0 && a->Cout % epc == 0, EESEG_ERR_ARG,
+                "conv_wgrad: Cin=%d / Cout=%d must be multiples of %d", a->Cin, a->Cout, epc);
+    EESEG_CHECK(a->N > 0 && a->Hin > 0 && a->Win > 0 && a->Hout > 0 && a->Wout > 0, EESEG_ERR_ARG,
+                "conv_wgrad: non-positive shape");
+    EESEG_CHECK(a->R * a->S >= 1 && a->stride >= 1 && a->dil >= 1, EESEG_ERR_ARG, "conv_wgrad: bad geometry");
+    const long long M = (long long)a->N * a->Hout * a->Wout;
+    const long long xbytes = (long long)a->N * a->Hin * a->Win * a->Cin * es;
+    const long long dybytes = M * a->Cout * es;
+    EESEG_CHECK(xbytes < (1ll << 31) && dybytes < (1ll << 31), EESEG_ERR_TOO_LARGE,
+                "conv_wgrad: tensor exceeds 2 GiB descriptor range");
+    EESEG_CHECK(((uintptr_t)a->x & 15) == 0 && ((uintptr_t)a->dy & 15) == 0 && ((uintptr_t)a->dw & 3) == 0,
+                EESEG_ERR_ARG, "conv_wgrad: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = a->R * a->S;
+    if (!a->accumulate)
+        EESEG_HIP(hipMemsetAsync(a->dw, 0, (size_t)a->Cout * taps * a->Cin * sizeof(float), st));
+
+    WgP p;
+    p.x = a->x; p.dy = a->dy; p.dw = a->dw;
+    p.N = a->N; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin;
+    p.Hout = a->Hout; p.Wout = a->Wout; p.Cout = a->Cout; p.R = a->R; p.S = a->S;
+    p.stride = a->stride; p.pad = a->pad; p.dil = a->dil; p.lddy = a->Cout;
+    p.M = (int)M; p.HWout = a->Hout * a->Wout;
+    p.co_tiles = (a->Cout + 127) / 128; p.ci_tiles = (a->Cin + 127) / 128;
+    p.xbytes = (uint32_t)xbytes; p.dybytes = (uint32_t)dybytes;
+    const int kp = 128 / es;
+    const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
+    long long splits = (1536 + tiles - 1) / tiles;            // aim at ~6 blocks per CU
+    const long long max_splits = (M + 4 * kp - 1) / (4 * kp); // at least 4 K steps per block
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long long chunk = (M + splits - 1) / splits;
+    chunk = (chunk + kp - 1) / kp * kp;
+    splits = (M + chunk - 1) / chunk;
+    p.splits = (int)splits; p.chunk = (int)chunk;
+    const long long grid = tiles * splits;
+    EESEG_CHECK(grid < (1ll << 31), EESEG_ERR_TOO_LARGE, "conv_wgrad: grid too large");
+    if (a->dtype == EESEG_BF16)
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}

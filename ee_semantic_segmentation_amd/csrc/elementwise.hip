@@ -1,0 +1,927 @@
+// HBM-bound kernels around the conv GEMMs: BatchNorm (finalize / apply / backward),
+// column reductions (wave + LDS, deterministic two-stage), pooling, packing.
+// Everything moves 16 bytes per lane; activations are NHWC rows [rows][C] with an
+// explicit row stride (ld, in elements) so channel slices of a wider tensor (the
+// ASPP concat buffer) are read/written in place.
+#include "eeseg_common.h"
+
+namespace {
+
+template <typename T> struct Vec {
+    static constexpr int N = 16 / (int)sizeof(T);
+    union { i32x4 q; T e[16 / sizeof(T)]; };
+};
+
+template <typename T> __device__ __forceinline__ Vec<T> ld16(const T* p) {
+    Vec<T> v; v.q = *reinterpret_cast<const i32x4*>(p); return v;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec<T>& v) {
+    *reinterpret_cast<i32x4*>(p) = v.q;
+}
+
+inline int ew_grid(long long work_items, int block = 256) {
+    long long b = (work_items + block - 1) / block;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// =========================================================================
+// pack / cast / im2col
+// =========================================================================
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* wf, T* wb, int Cout, int Cout_pad, int Cin,
+                                   int taps, int src_krsc) {
+    const long long total = (long long)Cout_pad * taps * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const long long r = i / Cin;
+        const int tap = (int)(r % taps);
+        const int co = (int)(r / taps);
+        float v = 0.f;
+        if (co < Cout) v = src_krsc ? src[((long long)co * taps + tap) * Cin + ci]
+                                    : src[((long long)co * Cin + ci) * taps + tap];
+        if (wf) wf[i] = from_f32<T>(v);
+        if (wb) wb[((long long)ci * taps + tap) * Cout_pad + co] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int cols, int lds, T* dst, int rows_pad,
+                                   int cols_pad) {
+    const long long total = (long long)rows_pad * cols_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols_pad);
+        const int r = (int)(i / cols_pad);
+        dst[i] = from_f32<T>((r < rows && c < cols) ? src[(long long)r * lds + c] : 0.f);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* y, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = from_f32<TO>(to_f32(x[i]));
+}
+
+template <typename T>
+__global__ void im2col_nchw_kernel(const float* __restrict__ x, T* col, int N, int C, int H, int W, int R, int S,
+                                   int stride, int pad, int Ho, int Wo, int Kpad) {
+    // one thread per (pixel, 8 consecutive k) -> 16/32-byte contiguous stores
+    const int KG = Kpad / 8;
+    const long long total = (long long)N * Ho * Wo * KG;
+    const int K = R * S * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int kg = (int)(i % KG);
+        const long long m = i / KG;
+        const int wo = (int)(m % Wo);
+        const long long t = m / Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        T out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kg * 8 + e;
+            float v = 0.f;
+            if (k < K) {
+                const int ci = k % C;
+                const int tap = k / C;
+                const int r = tap / S, s = tap - r * S;
+                const int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v = x[(((long long)n * C + ci) * H + hi) * W + wi];
+            }
+            out[e] = from_f32<T>(v);
+        }
+        T* dst = col + m * Kpad + kg * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = out[e];
+    }
+}
+
+// =========================================================================
+// column reductions: [rows][C] -> K sums per channel, two deterministic stages
+// block = (32 chunk-columns, 8 row lanes); grid = (col blocks, row blocks, batch)
+// =========================================================================
+struct StatsOp {   // sum x, sum x^2
+    static constexpr int K = 2;
+    template <typename T> struct Args { const T* x; int ldx; };
+};
+
+template <typename T, int K, typename F>
+__device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, long long row_end, int C,
+                                               float* out /* [K][C] for this (rowblock,batch) */) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float sred[8][32][K * EPC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int chunk = blockIdx.x * 32 + tx;
+    const int c0 = chunk * EPC;
+    float acc[K][EPC];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[k][e] = 0.f;
+    if (c0 < C) {
+        for (long long r = row_begin + ty; r < row_end; r += 8) elem(r, c0, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sred[ty][tx][k * EPC + e] = acc[k][e];
+    __syncthreads();
+    // 256 threads sum the 8 row lanes for 32*K*EPC values
+    const int t = ty * 32 + tx;
+    for (int v = t; v < 32 * K * EPC; v += 256) {
+        const int col = v / (K * EPC), ke = v - col * (K * EPC);
+        float s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) s += sred[y][col][ke];
+        const int k = ke / EPC, e = ke - k * EPC;
+        const int cg = (blockIdx.x * 32 + col) * EPC + e;
+        if (cg < C) out[(long long)k * C + cg] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stats_stage1(const T* x, int ldx, long long rows, long long rows_per_block,
+                                                    int C, float* partials) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long long rb = (long long)blockIdx.y * rows_per_block;
+    const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    colreduce_body<T, 2>(
+        [&](long long r, int c0, float (*acc)[EPC]) {
+            Vec<T> v = ld16(x + r * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float f = to_f32(v.e[e]);
+                acc[0][e] += f;
+                acc[1][e] += f * f;
+            }
+        },
+        rb, re, C, partials + (long long)blockIdx.y * 2 * C);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1(const T* x, int ldx, long long rows, long long rows_per_block,
+                                                     int C, float* partials) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long long rb = (long long)blockIdx.y * rows_per_block;
+    const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    colreduce_body<T, 1>(
+        [&](long long r, int c0, float (*acc)[EPC]) {
+            Vec<T> v = ld16(x + r * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[0][e] += to_f32(v.e[e]);
+        },
+        rb, re, C, partials + (long long)blockIdx.y * C);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, const T* y, int ldy, const T* x, int ldx,
+                                                     const float* mean_invstd, long long rows,
+                                                     long long rows_per_block, int C, int relu, float* partials) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long long rb = (long long)blockIdx.y * rows_per_block;
+    const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
+    const int c0t = (blockIdx.x * 32 + threadIdx.x) * EPC;
+    float mu[EPC], is[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const bool ok = c0t + e < C;
+        mu[e] = ok ? mean_invstd[c0t + e] : 0.f;
+        is[e] = ok ? mean_invstd[C + c0t + e] : 0.f;
+    }
+    colreduce_body<T, 2>(
+        [&](long long r, int c0, float (*acc)[EPC]) {
+            Vec<T> g = ld16(dy + r * lddy + c0);
+            Vec<T> xv = ld16(x + r * ldx + c0);
+            Vec<T> yv;
+            if (relu) yv = ld16(y + r * ldy + c0);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float gf = to_f32(g.e[e]);
+                if (relu && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+                const float xh = (to_f32(xv.e[e]) - mu[e]) * is[e];
+                acc[0][e] += gf;
+                acc[1][e] += gf * xh;
+            }
+        },
+        rb, re, C, partials + (long long)blockIdx.y * 2 * C);
+}
+
+// stage 2: partials[tiles][KC] -> out[KC]   (KC = K*C flattened), double accumulation
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int tiles, int KC,
+                                                              float* out) {
+    __shared__ double sred[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    double s = 0.0;
+    if (col < KC)
+        for (int t = g; t < tiles; t += 4) s += (double)partials[(long long)t * KC + col];
+    sred[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && col < KC) out[col] = (float)(sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
+                                               sred[3][threadIdx.x]);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean_invstd, float* scale_shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = (double)sums[c] / count;
+    double var = (double)sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (mean_invstd) {
+        mean_invstd[c] = (float)mean;
+        mean_invstd[C + c] = (float)invstd;
+    }
+    scale_shift[c] = (float)(g * invstd);
+    scale_shift[C + c] = (float)(b - mean * g * invstd);
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale_shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale_shift[c] = g * invstd;
+    scale_shift[C + c] = b - rm[c] * g * invstd;
+}
+
+// =========================================================================
+// elementwise passes over [rows][C] with row strides
+// =========================================================================
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
+                                                       const TI* res, int ldres, TO* y, int ldy, long long rows,
+                                                       int C, int relu) {
+    constexpr int EPC = 16 / (int)sizeof(TI);
+    const int cpr = C / EPC;
+    const long long total = rows * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const long long r = i / cpr;
+        const int c0 = ch * EPC;
+        Vec<TI> v = ld16(x + r * ldx + c0);
+        Vec<TI> rv;
+        if (res) rv = ld16(res + r * ldres + c0);
+        float o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float f = to_f32(v.e[e]) * ss[c0 + e] + ss[C + c0 + e];
+            if (res) f += to_f32(rv.e[e]);
+            if (relu) f = fmaxf(f, 0.f);
+            o[e] = f;
+        }
+        TO* dst = y + r * ldy + c0;
+        if constexpr (sizeof(TO) == sizeof(TI)) {
+            Vec<TO> w;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) w.e[e] = from_f32<TO>(o[e]);
+            st16(dst, w);
+        } else {   // bf16 in (8 elems) -> f32 out: two 16-byte stores
+            Vec<TO> w0, w1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w0.e[e] = from_f32<TO>(o[e]); w1.e[e] = from_f32<TO>(o[4 + e]); }
+            st16(dst, w0);
+            st16(dst + 4, w1);
+        }
+    }
+}
+
+// MODE 0: train BN backward (needs x, mean/invstd, gamma, sums); MODE 1: dx = g*scale
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy, const T* y, int ldy, const T* x,
+                                                           int ldx, const float* __restrict__ mean_invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, float inv_count, T* dx,
+                                                           int lddx, T* dres, int lddres, long long rows, int C,
+                                                           int relu) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cpr = C / EPC;
+    const long long total = rows * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const long long r = i / cpr;
+        const int c0 = ch * EPC;
+        Vec<T> g = ld16(dy + r * lddy + c0);
+        Vec<T> yv, xv;
+        if (relu) yv = ld16(y + r * ldy + c0);
+        if (MODE == 0) xv = ld16(x + r * ldx + c0);
+        Vec<T> od, og;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float gf = to_f32(g.e[e]);
+            if (relu && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+            og.e[e] = from_f32<T>(gf);
+            float d;
+            if (MODE == 0) {
+                const int c = c0 + e;
+                const float mu = mean_invstd[c], is = mean_invstd[C + c];
+                const float xh = (to_f32(xv.e[e]) - mu) * is;
+                const float ga = gamma ? gamma[c] : 1.f;
+                d = ga * is * (gf - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+            } else {
+                d = gf * gamma[c0 + e];   // gamma := scale
+            }
+            od.e[e] = from_f32<T>(d);
+        }
+        st16(dx + r * lddx + c0, od);
+        if (dres) st16(dres + r * lddres + c0, og);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* x, T* y, int N, int H, int W, int C, int Ho, int Wo) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cpr = C / EPC;
+    const long long total = (long long)N * Ho * Wo * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        long long t = i / cpr;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float m[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int wi = wo * 2 - 1 + s;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                Vec<T> v = ld16(x + (((long long)n * H + hi) * W + wi) * C + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], to_f32(v.e[e]));
+            }
+        }
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>(m[e]);
+        st16(y + (((long long)n * Ho + ho) * Wo + wo) * C + ch * EPC, o);
+    }
+}
+
+// dx[h,w] = sum over windows containing (h,w) whose FIRST maximum (scan order
+// r then s, strict >, as torch's CPU kernel) is (h,w).  No atomics, no index tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, int N, int H, int W, int C,
+                                                          int Ho, int Wo) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cpr = C / EPC;
+    const long long total = (long long)N * H * W * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        long long t = i / cpr;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        // windows: ho with 2ho-1 <= h <= 2ho+1
+        const int ho_lo = (h) / 2, ho_hi = (h + 1) / 2;
+        const int wo_lo = (w) / 2, wo_hi = (w + 1) / 2;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                float best[EPC];
+                int bidx[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bidx[e] = -1; }
+                for (int r = 0; r < 3; ++r) {
+                    const int hi = ho * 2 - 1 + r;
+                    if ((unsigned)hi >= (unsigned)H) continue;
+                    for (int s = 0; s < 3; ++s) {
+                        const int wi = wo * 2 - 1 + s;
+                        if ((unsigned)wi >= (unsigned)W) continue;
+                        Vec<T> v = ld16(x + (((long long)n * H + hi) * W + wi) * C + ch * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            const float f = to_f32(v.e[e]);
+                            if (f > best[e] || bidx[e] < 0) { best[e] = f; bidx[e] = hi * W + wi; }
+                        }
+                    }
+                }
+                Vec<T> g = ld16(dy + (((long long)n * Ho + ho) * Wo + wo) * C + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (bidx[e] == h * W + w) acc[e] += to_f32(g.e[e]);
+            }
+        }
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>(acc[e]);
+        st16(dx + (((long long)n * H + h) * W + w) * C + ch * EPC, o);
+    }
+}
+
+// per-image column sums: x[n][hw][ldx] -> y[n][C] * scale   (GAP forward, sum_hw)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_hw_kernel(const T* x, int ldx, T* y, int HW, int C, float scale) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float sred[8][32][EPC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, n = blockIdx.y;
+    const int c0 = (blockIdx.x * 32 + tx) * EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        for (int r = ty; r < HW; r += 8) {
+            Vec<T> v = ld16(x + ((long long)n * HW + r) * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += to_f32(v.e[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) sred[ty][tx][e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += sred[q][tx][e];
+            o.e[e] = from_f32<T>(s * scale);
+        }
+        st16(y + (long long)n * C + c0, o);
+    }
+}
+
+// y[n][hw][ldy slice] (+)= x[n][c] * scale
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_hw_kernel(const T* x, T* y, int ldy, int N, int HW, int C,
+                                                           float scale, int accumulate) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cpr = C / EPC;
+    const long long total = (long long)N * HW * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const long long r = i / cpr;
+        const int n = (int)(r / HW);
+        Vec<T> v = ld16(x + (long long)n * C + ch * EPC);
+        T* dst = y + r * ldy + ch * EPC;
+        Vec<T> o;
+        if (accumulate) {
+            Vec<T> old = ld16(dst);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>(to_f32(old.e[e]) + to_f32(v.e[e]) * scale);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>(to_f32(v.e[e]) * scale);
+        }
+        st16(dst, o);
+    }
+}
+
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long long n, float p, uint64_t seed) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long long chunks = n / EPC;
+    const float keep_scale = 1.f / (1.f - p);
+    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < chunks;
+         i += (long long)gridDim.x * blockDim.x) {
+        Vec<T> v = ld16(x + i * EPC);
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const uint32_t h = mix32(seed ^ (uint64_t)(i * EPC + e) * 0xD6E8FEB86659FD93ull) >> 8;
+            o.e[e] = from_f32<T>(h >= thr ? to_f32(v.e[e]) * keep_scale : 0.f);
+        }
+        st16(y + i * EPC, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* y, const T* x, long long n) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const long long chunks = n / EPC;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < chunks;
+         i += (long long)gridDim.x * blockDim.x) {
+        Vec<T> a = ld16(y + i * EPC), b = ld16(x + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) a.e[e] = from_f32<T>(to_f32(a.e[e]) + to_f32(b.e[e]));
+        st16(y + i * EPC, a);
+    }
+}
+
+// ---- host-side helpers ----------------------------------------------------
+struct RowSplit { int blocks; long long rows_per_block; };
+inline RowSplit row_split(long long rows) {
+    long long rpb = (rows + 1023) / 1024;
+    if (rpb < 64) rpb = 64;
+    RowSplit s;
+    s.rows_per_block = rpb;
+    s.blocks = (int)((rows + rpb - 1) / rpb);
+    if (s.blocks < 1) s.blocks = 1;
+    return s;
+}
+
+inline int check_rows(const char* name, const void* p, int ld, int C, int dtype) {
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    EESEG_CHECK(((uintptr_t)p & 15) == 0, EESEG_ERR_ARG, "%s: pointer not 16-byte aligned", name);
+    EESEG_CHECK(C % epc == 0 && ld % epc == 0 && ld >= C, EESEG_ERR_ARG, "%s: C=%d ld=%d must be multiples of %d", name,
+                C, ld, epc);
+    return EESEG_OK;
+}
+#define CHECK_ROWS(name, p, ld, C, dt)                          \
+    do {                                                        \
+        int rc_ = check_rows(name, p, ld, C, dt);               \
+        if (rc_) return rc_;                                    \
+    } while (0)
+
+}  // namespace
+
+// ==========================================================================
+// C ABI
+// ==========================================================================
+extern "C" int eeseg_pack_weight(const float* src, void* w_fwd, void* w_bwd, int Cout, int Cout_pad, int Cin, int R,
+                                 int S, int src_krsc, int dtype, void* stream) {
+    EESEG_CHECK(src && (w_fwd || w_bwd), EESEG_ERR_ARG, "pack_weight: null pointer");
+    EESEG_CHECK(Cout_pad >= Cout && Cout > 0 && Cin > 0 && R * S > 0, EESEG_ERR_ARG, "pack_weight: bad shape");
+    const long long total = (long long)Cout_pad * R * S * Cin;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, src, (bf16_t*)w_fwd,
+                           (bf16_t*)w_bwd, Cout, Cout_pad, Cin, R * S, src_krsc);
+    else if (dtype == EESEG_F32)
+        hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, src, (float*)w_fwd,
+                           (float*)w_bwd, Cout, Cout_pad, Cin, R * S, src_krsc);
+    else
+        EESEG_CHECK(false, EESEG_ERR_ARG, "pack_weight: bad dtype");
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_pack_matrix(const float* src, int rows, int cols, int ld_src, void* dst, int rows_pad,
+                                 int cols_pad, int dtype, void* stream) {
+    EESEG_CHECK(src && dst && rows_pad >= rows && cols_pad >= cols && ld_src >= cols, EESEG_ERR_ARG,
+                "pack_matrix: bad argument");
+    const long long total = (long long)rows_pad * cols_pad;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((pack_matrix_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, src, rows, cols,
+                           ld_src, (bf16_t*)dst, rows_pad, cols_pad);
+    else
+        hipLaunchKernelGGL((pack_matrix_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, src, rows, cols,
+                           ld_src, (float*)dst, rows_pad, cols_pad);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_im2col_nchw(const float* x, void* col, int N, int C, int H, int W, int R, int S, int stride,
+                                 int pad, int Ho, int Wo, int Kpad, int dtype, void* stream) {
+    EESEG_CHECK(x && col, EESEG_ERR_ARG, "im2col: null pointer");
+    EESEG_CHECK(Kpad % 8 == 0 && Kpad >= R * S * C, EESEG_ERR_ARG, "im2col: Kpad=%d must be a multiple of 8 >= %d", Kpad,
+                R * S * C);
+    EESEG_CHECK(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1, EESEG_ERR_ARG,
+                "im2col: inconsistent output size");
+    const long long total = (long long)N * Ho * Wo * (Kpad / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((im2col_nchw_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, x, (bf16_t*)col, N, C,
+                           H, W, R, S, stride, pad, Ho, Wo, Kpad);
+    else
+        hipLaunchKernelGGL((im2col_nchw_kernel<float>), dim3(ew_grid(total)), dim3(256), 0, st, x, (float*)col, N, C, H,
+                           W, R, S, stride, pad, Ho, Wo, Kpad);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, int64_t n, void* stream) {
+    EESEG_CHECK(x && y && n >= 0, EESEG_ERR_ARG, "cast: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = ew_grid(n);
+    if (in_dtype == EESEG_F32 && out_dtype == EESEG_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)x, (bf16_t*)y, n);
+    else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (float*)y, n);
+    else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, n);
+    else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+    else
+        EESEG_CHECK(false, EESEG_ERR_ARG, "cast: bad dtype");
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int64_t eeseg_colreduce_workspace(int64_t rows, int C) {
+    return (int64_t)row_split(rows).blocks * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* stream) {
+    EESEG_CHECK(partials && sums && tiles > 0 && KC > 0, EESEG_ERR_ARG, "bn_reduce_partials: bad argument");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((KC + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, tiles,
+                       KC, sums);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, float* mean_invstd,
+                                 float* scale_shift, int C, void* stream) {
+    EESEG_CHECK(sums && scale_shift && C > 0 && count > 0, EESEG_ERR_ARG, "bn_finalize: bad argument");
+    EESEG_CHECK((running_mean == nullptr) == (running_var == nullptr), EESEG_ERR_ARG,
+                "bn_finalize: running_mean/var must both be given or both be NULL");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count, gamma,
+                       beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift, C);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                                         const float* running_var, float eps, float* scale_shift, int C,
+                                         void* stream) {
+    EESEG_CHECK(running_mean && running_var && scale_shift && C > 0, EESEG_ERR_ARG, "bn_eval: bad argument");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, scale_shift, C);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
+                              void* y, int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype,
+                              void* stream) {
+    EESEG_CHECK(x && y && scale_shift && rows > 0, EESEG_ERR_ARG, "bn_apply: bad argument");
+    CHECK_ROWS("bn_apply x", x, ldx, C, in_dtype);
+    if (residual) CHECK_ROWS("bn_apply residual", residual, ldres, C, in_dtype);
+    EESEG_CHECK(((uintptr_t)y & 15) == 0 && ldy >= C && ldy % 4 == 0, EESEG_ERR_ARG, "bn_apply: bad y/ldy");
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(in_dtype);
+    const int g = ew_grid(rows * (C / epc));
+    if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
+        EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu);
+    } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu);
+    } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
+        hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu);
+    } else {
+        EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
+    }
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+// launches stage1 via `launch1(grid, partial_ptr)` then stage 2 when needed
+template <typename L>
+static int two_stage(L&& launch1, int64_t rows, int C, int K, int epc, float* out, void* workspace,
+                     int64_t workspace_bytes, hipStream_t st) {
+    const RowSplit rs = row_split(rows);
+    const int colblocks = (C / epc + 31) / 32;
+    float* partials = out;
+    if (rs.blocks > 1) {
+        EESEG_CHECK(workspace && workspace_bytes >= (int64_t)rs.blocks * K * C * (int64_t)sizeof(float), EESEG_ERR_ARG,
+                    "column reduce: workspace too small (%lld bytes needed)",
+                    (long long)rs.blocks * K * C * (long long)sizeof(float));
+        partials = (float*)workspace;
+    }
+    launch1(dim3(colblocks, rs.blocks), rs.rows_per_block, partials);
+    EESEG_LAUNCH_CHECK();
+    if (rs.blocks > 1) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, partials, rs.blocks, K * C,
+                           out);
+        EESEG_LAUNCH_CHECK();
+    }
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    EESEG_CHECK(x && sums && rows > 0, EESEG_ERR_ARG, "channel_stats: bad argument");
+    CHECK_ROWS("channel_stats", x, ldx, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        return two_stage([&](dim3 g, long long rpb, float* part) {
+            hipLaunchKernelGGL((stats_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (long long)rows, rpb,
+                               C, part);
+        }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
+    return two_stage([&](dim3 g, long long rpb, float* part) {
+        hipLaunchKernelGGL((stats_stage1<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (long long)rows, rpb, C,
+                           part);
+    }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
+}
+
+extern "C" int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* out, int dtype, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    EESEG_CHECK(x && out && rows > 0, EESEG_ERR_ARG, "colsum: bad argument");
+    CHECK_ROWS("colsum", x, ldx, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        return two_stage([&](dim3 g, long long rpb, float* part) {
+            hipLaunchKernelGGL((colsum_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (long long)rows,
+                               rpb, C, part);
+        }, rows, C, 1, 8, out, workspace, workspace_bytes, st);
+    return two_stage([&](dim3 g, long long rpb, float* part) {
+        hipLaunchKernelGGL((colsum_stage1<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (long long)rows, rpb, C,
+                           part);
+    }, rows, C, 1, 4, out, workspace, workspace_bytes, st);
+}
+
+extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                   const float* mean_invstd, int64_t rows, int C, int relu, float* sums, int dtype,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && (!relu || y), EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
+    CHECK_ROWS("bn_bwd_reduce dy", dy, lddy, C, dtype);
+    CHECK_ROWS("bn_bwd_reduce x", x, ldx, C, dtype);
+    if (relu) CHECK_ROWS("bn_bwd_reduce y", y, ldy, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16)
+        return two_stage([&](dim3 g, long long rpb, float* part) {
+            hipLaunchKernelGGL((bn_bwd_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)y,
+                               ldy, (const bf16_t*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, part);
+        }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
+    return two_stage([&](dim3 g, long long rpb, float* part) {
+        hipLaunchKernelGGL((bn_bwd_stage1<float>), g, dim3(32, 8), 0, st, (const float*)dy, lddy, (const float*)y, ldy,
+                           (const float*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, part);
+    }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
+}
+
+extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                  const float* mean_invstd, const float* gamma, const float* sums, double count,
+                                  void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
+                                  void* stream) {
+    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && (!relu || y), EESEG_ERR_ARG,
+                "bn_bwd_apply: bad argument");
+    CHECK_ROWS("bn_bwd_apply dy", dy, lddy, C, dtype);
+    CHECK_ROWS("bn_bwd_apply x", x, ldx, C, dtype);
+    CHECK_ROWS("bn_bwd_apply dx", dx, lddx, C, dtype);
+    if (relu) CHECK_ROWS("bn_bwd_apply y", y, ldy, C, dtype);
+    if (dres) CHECK_ROWS("bn_bwd_apply dres", dres, lddres, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    const int g = ew_grid(rows * (C / epc));
+    const float inv = (float)(1.0 / count);
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
+                           (float*)dres, lddres, (long long)rows, C, relu);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int ldy, const float* scale, void* dx,
+                                   int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
+                                   void* stream) {
+    EESEG_CHECK(dy && scale && dx && rows > 0 && (!relu || y), EESEG_ERR_ARG, "scale_act_bwd: bad argument");
+    CHECK_ROWS("scale_act_bwd dy", dy, lddy, C, dtype);
+    CHECK_ROWS("scale_act_bwd dx", dx, lddx, C, dtype);
+    if (relu) CHECK_ROWS("scale_act_bwd y", y, ldy, C, dtype);
+    if (dres) CHECK_ROWS("scale_act_bwd dres", dres, lddres, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    const int g = ew_grid(rows * (C / epc));
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype,
+                                  void* stream) {
+    EESEG_CHECK(x && y, EESEG_ERR_ARG, "maxpool: null pointer");
+    EESEG_CHECK(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, EESEG_ERR_ARG, "maxpool: bad output size");
+    CHECK_ROWS("maxpool x", x, C, C, dtype);
+    CHECK_ROWS("maxpool y", y, C, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    const int g = ew_grid((long long)N * Ho * Wo * (C / epc));
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C,
+                           Ho, Wo);
+    else
+        hipLaunchKernelGGL((maxpool_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, Ho,
+                           Wo);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho,
+                                      int Wo, int dtype, void* stream) {
+    EESEG_CHECK(x && dy && dx, EESEG_ERR_ARG, "maxpool_bwd: null pointer");
+    EESEG_CHECK(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, EESEG_ERR_ARG, "maxpool_bwd: bad output size");
+    CHECK_ROWS("maxpool_bwd x", x, C, C, dtype);
+    CHECK_ROWS("maxpool_bwd dy", dy, C, C, dtype);
+    CHECK_ROWS("maxpool_bwd dx", dx, C, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    const int g = ew_grid((long long)N * H * W * (C / epc));
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
+                           (bf16_t*)dx, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)dy,
+                           (float*)dx, N, H, W, C, Ho, Wo);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype,
+                            void* stream) {
+    EESEG_CHECK(x && y && N > 0 && HW > 0, EESEG_ERR_ARG, "sum_hw: bad argument");
+    CHECK_ROWS("sum_hw x", x, ldx, C, dtype);
+    CHECK_ROWS("sum_hw y", y, C, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    dim3 g((C / epc + 31) / 32, N);
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((sum_hw_kernel<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, HW, C, scale);
+    else
+        hipLaunchKernelGGL((sum_hw_kernel<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (float*)y, HW, C, scale);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW, int C, float scale, int accumulate,
+                                  int dtype, void* stream) {
+    EESEG_CHECK(x && y && N > 0 && HW > 0, EESEG_ERR_ARG, "broadcast_hw: bad argument");
+    CHECK_ROWS("broadcast_hw x", x, C, C, dtype);
+    CHECK_ROWS("broadcast_hw y", y, ldy, C, dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    const int g = ew_grid((long long)N * HW * (C / epc));
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((broadcast_hw_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, ldy, N,
+                           HW, C, scale, accumulate);
+    else
+        hipLaunchKernelGGL((broadcast_hw_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, ldy, N, HW,
+                           C, scale, accumulate);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+    EESEG_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f, EESEG_ERR_ARG, "dropout: bad argument");
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    EESEG_CHECK(n % epc == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, EESEG_ERR_ARG,
+                "dropout: n must be a multiple of %d and pointers 16-byte aligned", epc);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = ew_grid(n / epc);
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long long)n,
+                           p, seed);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, (long long)n, p,
+                           seed);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream) {
+    EESEG_CHECK(x && y && n > 0, EESEG_ERR_ARG, "add_inplace: bad argument");
+    const int epc = 16 / eeseg_dtype_size(dtype);
+    EESEG_CHECK(n % epc == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, EESEG_ERR_ARG,
+                "add_inplace: n must be a multiple of %d and pointers 16-byte aligned", epc);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = ew_grid(n / epc);
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((add_inplace_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (bf16_t*)y, (const bf16_t*)x,
+                           (long long)n);
+    else
+        hipLaunchKernelGGL((add_inplace_kernel<float>), dim3(g), dim3(256), 0, st, (float*)y, (const float*)x,
+                           (long long)n);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}

@@ -1,0 +1,426 @@
+// Fused bilinear-upsample + per-pixel heads for the early-exit outputs (gfx950).
+//
+// The exits produce low-resolution logits [N,h,w,ldc] (NHWC fp32, C <= 32 valid
+// channels, row = 128 bytes when ldc == 32).  The reference upsamples every exit to
+// the input size and stacks [E,B,C,H,W] before the loss / argmax / entropy
+// (from_deepv3_new.py:149-155, my_pixelwise_xentropy.py:36-38, seg_metrics.py:13-28,
+// eval_br_ent.py:58-60).  These kernels interpolate on the fly instead: a 32-lane
+// half wave owns one full-resolution pixel (lane = class), so the 4 neighbour rows
+// are 128-byte coalesced loads and softmax / argmax are half-wave DPP reductions.
+#include "eeseg_common.h"
+
+namespace {
+
+constexpr int CMAX = 32;
+
+// torch's area_pixel_compute_source_index(align_corners=False) + guard_index_and_lambda
+struct Src { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Src src_index(int dst, float scale, int in_size) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int i0 = (int)floorf(s);
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float l1 = s - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    Src r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}
+
+__device__ __forceinline__ float half_max(float v) {   // reduce over the 32-lane half wave
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// interpolated logit of class `c` at full-res pixel (y,x) of image n
+__device__ __forceinline__ float interp(const float* __restrict__ lr, int ldc, int h, int w, int n, const Src& sy,
+                                        const Src& sx, int c) {
+    const float* base = lr + (size_t)n * h * w * ldc + c;
+    const float v00 = base[((size_t)sy.i0 * w + sx.i0) * ldc];
+    const float v01 = base[((size_t)sy.i0 * w + sx.i1) * ldc];
+    const float v10 = base[((size_t)sy.i1 * w + sx.i0) * ldc];
+    const float v11 = base[((size_t)sy.i1 * w + sx.i1) * ldc];
+    return sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11);
+}
+
+// ---------------------------------------------------------------- upsample ----
+__global__ __launch_bounds__(256) void upsample_nchw_kernel(const float* __restrict__ lr, int ldc, float* out, int N,
+                                                            int C, int h, int w, int H, int W) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)N * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long long t = i / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        float* o = out + ((size_t)n * C * H + y) * W + x;
+        for (int c = 0; c < C; ++c) o[(size_t)c * H * W] = interp(lr, ldc, h, w, n, sy, sx, c);
+    }
+}
+
+// gather form of the transposed interpolation: one thread per low-res (n,c,yi,xi)
+__global__ __launch_bounds__(256) void upsample_nchw_bwd_kernel(const float* __restrict__ dout, float* dlr, int ldc,
+                                                                int N, int C, int h, int w, int H, int W) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)N * h * w * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int xi = (int)(t % w); t /= w;
+        const int yi = (int)(t % h);
+        const int n = (int)(t / h);
+        // conservative full-res window that can touch (yi, xi)
+        int y_lo = (int)floorf(((float)yi - 1.f + 0.5f) / sh - 0.5f) - 1;
+        int y_hi = (int)ceilf(((float)yi + 1.f + 0.5f) / sh - 0.5f) + 1;
+        int x_lo = (int)floorf(((float)xi - 1.f + 0.5f) / sw - 0.5f) - 1;
+        int x_hi = (int)ceilf(((float)xi + 1.f + 0.5f) / sw - 0.5f) + 1;
+        y_lo = max(y_lo, 0); x_lo = max(x_lo, 0);
+        y_hi = min(y_hi, H - 1); x_hi = min(x_hi, W - 1);
+        const float* src = dout + ((size_t)n * C + c) * H * W;
+        float acc = 0.f;
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const Src sy = src_index(y, sh, h);
+            const float wy = (sy.i0 == yi ? sy.l0 : 0.f) + (sy.i1 == yi ? sy.l1 : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int x = x_lo; x <= x_hi; ++x) {
+                const Src sx = src_index(x, sw, w);
+                const float wx = (sx.i0 == xi ? sx.l0 : 0.f) + (sx.i1 == xi ? sx.l1 : 0.f);
+                if (wx != 0.f) row += wx * src[(size_t)y * W + x];
+            }
+            acc += wy * row;
+        }
+        dlr[(((size_t)n * h + yi) * w + xi) * ldc + c] = acc;
+    }
+}
+
+// ------------------------------------------------------ cross entropy fwd ----
+// accum (double[2]): [0] += sum over valid pixels of (lse - z[target]); [1] += #valid
+__global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __restrict__ lr, int ldc,
+                                                              const int64_t* __restrict__ target, int N, int C, int h,
+                                                              int w, int H, int W, long long ignore_index,
+                                                              double* accum) {
+    __shared__ float sl[8];
+    __shared__ float sc[8];
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;                 // 8 half waves per block
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)N * H * W;
+    float loss_acc = 0.f, cnt_acc = 0.f;
+    const bool active = lane32 < C;
+    for (long long p = (long long)blockIdx.x * 8 + half; p < total; p += (long long)gridDim.x * 8) {
+        const int x = (int)(p % W);
+        const long long t = p / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const long long tg = target[p];
+        if (tg == ignore_index || tg < 0 || tg >= C) continue;   // half-wave uniform
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        const float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        const float m = half_max(z);
+        const float e = active ? __expf(z - m) : 0.f;
+        const float s = half_sum(e);
+        const float zt = __shfl(z, (int)tg, 32);
+        loss_acc += (m + __logf(s)) - zt;
+        cnt_acc += 1.f;
+    }
+    // every lane of a half wave carries the same partial; reduce over the 8 halves
+    if (lane32 == 0) { sl[half] = loss_acc; sc[half] = cnt_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double l = 0.0, c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { l += (double)sl[i]; c += (double)sc[i]; }
+        if (c > 0.0) {
+            atomicAdd(&accum[0], l);
+            atomicAdd(&accum[1], c);
+        }
+    }
+}
+
+// ------------------------------------------------------ cross entropy bwd ----
+// One half wave per (n, y, x0): the full-res pixels of row y whose left source
+// column is x0 (a contiguous span) are reduced in registers into the two columns
+// x0 / x0+1, then scattered to the two source rows with 128-byte float atomics.
+__global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __restrict__ lr, int ldc,
+                                                              const int64_t* __restrict__ target, int N, int C, int h,
+                                                              int w, int H, int W, long long ignore_index,
+                                                              const double* __restrict__ accum, float gscale,
+                                                              float* dlr) {
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const double cnt = accum[1];
+    if (!(cnt > 0.0)) return;
+    const float g = (float)((double)gscale / cnt);
+    const bool active = lane32 < C;
+    const long long total = (long long)N * H * w;
+    for (long long it = (long long)blockIdx.x * 8 + half; it < total; it += (long long)gridDim.x * 8) {
+        const int x0 = (int)(it % w);
+        const long long t = it / w;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        // span of x with floor(src(x)) == x0 : invert src = sw*(x+0.5)-0.5 conservatively, then test
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = max(xa, 0); xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        float a0 = 0.f, a1 = 0.f;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;                               // uniform over the half wave
+            const long long tg = target[((long long)n * H + y) * W + x];
+            if (tg == ignore_index || tg < 0 || tg >= C) continue;   // uniform
+            const float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float s = half_sum(e);
+            float r = e / s;
+            if (lane32 == (int)tg) r -= 1.f;
+            if (sx.i1 == sx.i0) {
+                a0 += r;                    // clamped right border: both taps on x0
+            } else {
+                a0 += sx.l0 * r;
+                a1 += sx.l1 * r;
+            }
+        }
+        if (!active) continue;
+        const int x1 = min(x0 + 1, w - 1);
+        float* r0 = dlr + (((size_t)n * h + sy.i0) * w) * ldc + lane32;
+        float* r1 = dlr + (((size_t)n * h + sy.i1) * w) * ldc + lane32;
+        const float wy0 = (sy.i1 == sy.i0) ? 1.f : sy.l0;
+        const float wy1 = (sy.i1 == sy.i0) ? 0.f : sy.l1;
+        if (a0 != 0.f) {
+            atomicAdd(r0 + (size_t)x0 * ldc, g * wy0 * a0);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x0 * ldc, g * wy1 * a0);
+        }
+        if (a1 != 0.f) {
+            atomicAdd(r0 + (size_t)x1 * ldc, g * wy0 * a1);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x1 * ldc, g * wy1 * a1);
+        }
+    }
+}
+
+// ------------------------------------------------- argmax + TP/FP/FN counts ----
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ lr, int ldc,
+                                                               const int64_t* __restrict__ target, int N, int C, int h,
+                                                               int w, int H, int W, int* counts, int64_t* pred) {
+    __shared__ int sc[3 * CMAX];
+    for (int i = threadIdx.x; i < 3 * CMAX; i += blockDim.x) sc[i] = 0;
+    __syncthreads();
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)N * H * W;
+    const bool active = lane32 < C;
+    for (long long p = (long long)blockIdx.x * 8 + half; p < total; p += (long long)gridDim.x * 8) {
+        const int x = (int)(p % W);
+        const long long t = p / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        int idx = lane32;
+        // first maximum wins (torch.argmax): on ties keep the smaller index
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float oz = __shfl_xor(z, o);
+            const int oi = __shfl_xor(idx, o);
+            if (oz > z || (oz == z && oi < idx)) { z = oz; idx = oi; }
+        }
+        if (lane32 == 0) {
+            if (pred) pred[p] = idx;
+            if (target) {
+                const long long tg = target[p];
+                if (tg >= 0 && tg < C) {
+                    if (tg == idx) atomicAdd(&sc[idx], 1);
+                    else { atomicAdd(&sc[CMAX + idx], 1); atomicAdd(&sc[2 * CMAX + (int)tg], 1); }
+                } else {
+                    atomicAdd(&sc[CMAX + idx], 1);     // void pixel counts as FP of the prediction (B-9)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (counts)
+        for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+            const int k = i / C, c = i - k * C;
+            const int v = sc[k * CMAX + c];
+            if (v) atomicAdd(&counts[k * C + c], v);
+        }
+}
+
+// ---------------------------------------------------------- entropy gate ----
+__global__ __launch_bounds__(256) void entropy_map_kernel(const float* __restrict__ lr, int ldc, int N, int C, int h,
+                                                          int w, int H, int W, float* emap) {
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const float inv_logc = 1.f / logf((float)C);
+    const long long total = (long long)N * H * W;
+    const bool active = lane32 < C;
+    for (long long p = (long long)blockIdx.x * 8 + half; p < total; p += (long long)gridDim.x * 8) {
+        const int x = (int)(p % W);
+        const long long t = p / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        const float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        const float m = half_max(z);
+        const float e = active ? expf(z - m) : 0.f;
+        const float s = half_sum(e);
+        // H = -sum p ln p = ln(s) - sum e*(z-m)/s      (p = e/s)
+        const float ez = active ? e * (z - m) : 0.f;
+        const float sez = half_sum(ez);
+        if (lane32 == 0) emap[p] = (logf(s) - sez / s) * inv_logc;
+    }
+}
+
+// one block per image: mean of the entropy map, or of its s x s max/min block pool
+// (zero padded to a multiple of s, skimage.block_reduce semantics).
+__global__ __launch_bounds__(1024) void entropy_reduce_kernel(const float* __restrict__ emap, int H, int W, int pool,
+                                                              int s, float tau, float* ent_out, int* flag_out) {
+    __shared__ double sred[16];
+    const int n = blockIdx.x;
+    const float* e = emap + (size_t)n * H * W;
+    double acc = 0.0;
+    long long count;
+    if (pool == 0 || s <= 1) {
+        count = (long long)H * W;
+        for (long long i = threadIdx.x; i < count; i += blockDim.x) acc += (double)e[i];
+    } else {
+        const int Hb = (H + s - 1) / s, Wb = (W + s - 1) / s;
+        count = (long long)Hb * Wb;
+        for (long long b = threadIdx.x; b < count; b += blockDim.x) {
+            const int by = (int)(b / Wb), bx = (int)(b % Wb);
+            float v = (pool == 1) ? -INFINITY : INFINITY;
+            for (int dy = 0; dy < s; ++dy)
+                for (int dx = 0; dx < s; ++dx) {
+                    const int y = by * s + dy, x = bx * s + dx;
+                    const float f = (y < H && x < W) ? e[(size_t)y * W + x] : 0.f;   // zero padding
+                    v = (pool == 1) ? fmaxf(v, f) : fminf(v, f);
+                }
+            acc += (double)v;
+        }
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sred[i];
+        const float ent = (float)(t / (double)count);
+        ent_out[n] = ent;
+        if (flag_out) flag_out[n] = ent < tau ? 1 : 0;
+    }
+}
+
+inline int px_grid(long long items) {   // 8 half waves per 256-thread block
+    long long b = (items + 7) / 8;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+inline int check_lr(const char* name, const float* lr, int ldc, int N, int C, int h, int w, int H, int W) {
+    EESEG_CHECK(lr != nullptr, EESEG_ERR_ARG, "%s: null logits", name);
+    EESEG_CHECK(N > 0 && h > 0 && w > 0 && H > 0 && W > 0, EESEG_ERR_ARG, "%s: non-positive shape", name);
+    EESEG_CHECK(C >= 1 && C <= CMAX && ldc >= C, EESEG_ERR_ARG, "%s: C=%d (max %d), ldc=%d", name, C, CMAX, ldc);
+    return EESEG_OK;
+}
+#define CHECK_LR(name)                                              \
+    do {                                                            \
+        int rc_ = check_lr(name, logits_lr, ldc, N, C, h, w, H, W); \
+        if (rc_) return rc_;                                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" int eeseg_upsample_bilinear_nchw(const float* logits_lr, int ldc, float* out, int N, int C, int h, int w,
+                                            int H, int W, void* stream) {
+    CHECK_LR("upsample_bilinear_nchw");
+    EESEG_CHECK(out != nullptr, EESEG_ERR_ARG, "upsample_bilinear_nchw: null output");
+    long long b = ((long long)N * H * W + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    hipLaunchKernelGGL(upsample_nchw_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc, out, N,
+                       C, h, w, H, W);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_upsample_bilinear_nchw_bwd(const float* dout, float* dlogits_lr, int ldc, int N, int C, int h,
+                                                int w, int H, int W, void* stream) {
+    EESEG_CHECK(dout && dlogits_lr && N > 0 && C > 0 && ldc >= C && h > 0 && w > 0 && H > 0 && W > 0, EESEG_ERR_ARG,
+                "upsample_bilinear_nchw_bwd: bad argument");
+    long long b = ((long long)N * h * w * C + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    hipLaunchKernelGGL(upsample_nchw_bwd_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dout, dlogits_lr,
+                       ldc, N, C, h, w, H, W);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
+                                     int H, int W, int64_t ignore_index, double* accum, void* stream) {
+    CHECK_LR("upsample_ce_fwd");
+    EESEG_CHECK(target && accum && ((uintptr_t)accum & 7) == 0, EESEG_ERR_ARG, "upsample_ce_fwd: bad target/accum");
+    hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
+                                     int H, int W, int64_t ignore_index, const double* accum, float gscale,
+                                     float* dlogits_lr, void* stream) {
+    CHECK_LR("upsample_ce_bwd");
+    EESEG_CHECK(target && accum && dlogits_lr, EESEG_ERR_ARG, "upsample_ce_bwd: null pointer");
+    hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3(px_grid((long long)N * H * w)), dim3(256), 0, (hipStream_t)stream,
+                       logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum, gscale, dlogits_lr);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h,
+                                      int w, int H, int W, int32_t* counts, int64_t* pred, void* stream) {
+    CHECK_LR("argmax_confusion");
+    EESEG_CHECK((counts && target) || pred, EESEG_ERR_ARG, "argmax_confusion: nothing to compute");
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       logits_lr, ldc, target, N, C, h, w, H, W, (int*)counts, pred);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int64_t eeseg_entropy_gate_workspace(int N, int H, int W) {
+    return (int64_t)N * H * W * (int64_t)sizeof(float);
+}
+
+extern "C" int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W, int pool,
+                                  int pool_size, float tau, float* entropy_out, int32_t* exit_flag, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    CHECK_LR("entropy_gate");
+    EESEG_CHECK(C >= 2, EESEG_ERR_ARG, "entropy_gate: needs at least 2 classes");
+    EESEG_CHECK(entropy_out && workspace && workspace_bytes >= eeseg_entropy_gate_workspace(N, H, W), EESEG_ERR_ARG,
+                "entropy_gate: workspace too small");
+    EESEG_CHECK(pool >= 0 && pool <= 2 && pool_size >= 1, EESEG_ERR_ARG, "entropy_gate: bad pooling mode");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(entropy_map_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, st, logits_lr, ldc, N, C,
+                       h, w, H, W, (float*)workspace);
+    EESEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(entropy_reduce_kernel, dim3(N), dim3(1024), 0, st, (const float*)workspace, H, W, pool, pool_size,
+                       tau, entropy_out, (int*)exit_flag);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}

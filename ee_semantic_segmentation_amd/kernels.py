@@ -1,0 +1,426 @@
+"""Tensor-level wrappers over the libeeseg C ABI.
+
+Every function here launches hand-written HIP kernels on torch's current stream
+and returns torch tensors that merely own the device memory.  Activations are
+NHWC tensors [N,H,W,C] (possibly a channel slice of a wider buffer: the last
+dim is contiguous and every other dim is dense over the row stride).
+No function falls back to torch arithmetic.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvArgs, WgradArgs, check, lib
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise _lib.EesegError(f"unsupported dtype {t.dtype}")
+
+
+def _tdt(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EesegError("libeeseg kernels need device tensors (no CPU fallback)")
+
+
+def rows_ld(t):
+    """(rows, C, ld) of an NHWC tensor/slice; checks the layout is row-strided."""
+    C_ = t.shape[-1]
+    if t.stride(-1) != 1 and C_ != 1:
+        raise _lib.EesegError("channel dim must be contiguous")
+    rows = t.numel() // C_
+    ld, exp = None, None
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] == 1:
+            continue
+        if ld is None:
+            ld = t.stride(d)
+            exp = ld * t.shape[d]
+        else:
+            if t.stride(d) != exp:
+                raise _lib.EesegError(
+                    f"tensor is not densely row-strided: shape {tuple(t.shape)} stride {t.stride()}")
+            exp *= t.shape[d]
+    if ld is None:
+        ld = C_
+    if ld < C_:
+        raise _lib.EesegError(f"row stride {ld} < channels {C_}")
+    return rows, C_, ld
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    key = str(device)
+    t = _ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 24), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ------------------------------------------------------------------ conv ----
+def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tstep, sdiv, ldy,
+               scale=None, shift=None, residual=None, ldres=0, stats=None, relu=False):
+    a = ConvArgs()
+    a.x, a.w, a.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    a.scale = 0 if scale is None else scale.data_ptr()
+    a.shift = 0 if shift is None else shift.data_ptr()
+    a.residual = 0 if residual is None else residual.data_ptr()
+    a.stats = 0 if stats is None else stats.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, Hin, Win, Cin, Hout, Wout, Cout, R, S
+    a.smul, a.off_h, a.off_w, a.tstep_h, a.tstep_w, a.sdiv = smul, off, off, tstep, tstep, sdiv
+    a.ldy, a.ldres, a.relu, a.dtype = ldy, ldres, int(relu), _dt(x)
+    check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
+
+
+def conv_fwd(x, w, stride=1, pad=0, dil=1, *, want_stats=False, scale=None, shift=None, residual=None,
+             relu=False, out=None):
+    """x [N,H,W,Cin]; w packed KRSC [Cout,R,S,Cin] in x.dtype.  Returns (y, partials|None)."""
+    _need_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w.shape
+    assert Cin2 == Cin and x.is_contiguous() and w.is_contiguous() and w.dtype == x.dtype
+    Ho, Wo = conv_out_size(H, R, stride, pad, dil), conv_out_size(W, S, stride, pad, dil)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    assert out.shape == (N, Ho, Wo, Cout) and out.dtype == x.dtype
+    _, _, ldy = rows_ld(out)
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype
+        _, _, ldres = rows_ld(residual)
+    partials = None
+    if want_stats:
+        tiles = lib().eeseg_conv_stats_tiles(N, Ho, Wo)
+        partials = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
+    _conv_call(x, w, out, N, H, W, Cin, Ho, Wo, Cout, R, S, stride, -pad, dil, 1, ldy, scale, shift, residual,
+               ldres, partials, relu)
+    return out, partials
+
+
+def conv_dgrad(dy, w_bwd, in_hw, stride=1, pad=0, dil=1, *, accumulate_into=None):
+    """dy [N,Ho,Wo,Cout]; w_bwd packed CRSK [Cin,R,S,Cout].  Returns dx [N,H,W,Cin]
+    (added into `accumulate_into` in place when given)."""
+    _need_cuda(dy, w_bwd)
+    N, Ho, Wo, Cout = dy.shape
+    Cin, R, S, Cout2 = w_bwd.shape
+    assert Cout2 == Cout and dy.is_contiguous() and w_bwd.is_contiguous() and w_bwd.dtype == dy.dtype
+    H, W = in_hw
+    if accumulate_into is not None:
+        dx = accumulate_into
+        assert dx.shape == (N, H, W, Cin) and dx.dtype == dy.dtype
+        res = dx
+    else:
+        dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
+        res = None
+    _, _, ld = rows_ld(dx)
+    _conv_call(dy, w_bwd, dx, N, Ho, Wo, Cout, H, W, Cin, R, S, 1, pad, -dil, stride, ld, residual=res,
+               ldres=ld if res is not None else 0)
+    return dx
+
+
+def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=False):
+    """Returns dw fp32 KRSC [Cout,R,S,Cin]."""
+    _need_cuda(x, dy)
+    N, H, W, Cin = x.shape
+    N2, Ho, Wo, Cout = dy.shape
+    assert N2 == N and x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    if out is None:
+        out = torch.empty((Cout, R, S, Cin), dtype=torch.float32, device=x.device)
+        accumulate = False
+    assert out.is_contiguous() and out.numel() == Cout * R * S * Cin and out.dtype == torch.float32
+    a = WgradArgs()
+    a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cin, Ho, Wo, Cout, R, S
+    a.stride, a.pad, a.dil, a.dtype, a.accumulate = stride, pad, dil, _dt(x), int(accumulate)
+    check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
+    return out
+
+
+def pack_weight(w, dtype, cout_pad=None, want_fwd=True, want_bwd=True):
+    """w: fp32 parameter [Cout,Cin,R,S] (torch default or channels_last strides).
+    Returns (w_fwd [Cout_pad,R,S,Cin], w_bwd [Cin,R,S,Cout_pad]) in `dtype`."""
+    _need_cuda(w)
+    Cout, Cin, R, S = w.shape
+    cp = cout_pad or Cout
+    if w.is_contiguous():
+        krsc = 1 if (R == 1 and S == 1) else 0
+    elif w.is_contiguous(memory_format=torch.channels_last):
+        krsc = 1
+    else:
+        raise _lib.EesegError("weight must be contiguous or channels_last")
+    wf = torch.empty((cp, R, S, Cin), dtype=dtype, device=w.device) if want_fwd else None
+    wb = torch.empty((Cin, R, S, cp), dtype=dtype, device=w.device) if want_bwd else None
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(lib().eeseg_pack_weight(_p(w), _p(wf), _p(wb), Cout, cp, Cin, R, S, krsc, code, _stream()),
+          "eeseg_pack_weight")
+    return wf, wb
+
+
+def pack_matrix(src, rows_pad, cols_pad, dtype):
+    _need_cuda(src)
+    rows, cols = src.shape
+    assert src.stride(1) == 1 and src.dtype == torch.float32
+    dst = torch.empty((rows_pad, cols_pad), dtype=dtype, device=src.device)
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(lib().eeseg_pack_matrix(_p(src), rows, cols, src.stride(0), _p(dst), rows_pad, cols_pad, code, _stream()),
+          "eeseg_pack_matrix")
+    return dst
+
+
+def im2col_nchw(x, R, S, stride, pad, kpad, dtype):
+    """x [N,C,H,W] fp32 NCHW -> col [N,Ho,Wo,Kpad] in dtype."""
+    _need_cuda(x)
+    N, Cc, H, W = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    Ho, Wo = conv_out_size(H, R, stride, pad, 1), conv_out_size(W, S, stride, pad, 1)
+    col = torch.empty((N, Ho, Wo, kpad), dtype=dtype, device=x.device)
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(lib().eeseg_im2col_nchw(_p(x), _p(col), N, Cc, H, W, R, S, stride, pad, Ho, Wo, kpad, code, _stream()),
+          "eeseg_im2col_nchw")
+    return col
+
+
+# ------------------------------------------------------------- batchnorm ----
+def reduce_partials(partials):
+    """[tiles, ...] fp32 -> [...] summed over tiles (fixed order)."""
+    tiles = partials.shape[0]
+    kc = partials[0].numel()
+    out = torch.empty(partials.shape[1:], dtype=torch.float32, device=partials.device)
+    check(lib().eeseg_bn_reduce_partials(_p(partials), tiles, kc, _p(out), _stream()), "eeseg_bn_reduce_partials")
+    return out
+
+
+def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var):
+    Cc = sums.shape[1]
+    mean_invstd = torch.empty((2, Cc), dtype=torch.float32, device=sums.device)
+    scale_shift = torch.empty((2, Cc), dtype=torch.float32, device=sums.device)
+    check(lib().eeseg_bn_finalize(_p(sums), float(count), _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+                                  _p(running_var), _p(mean_invstd), _p(scale_shift), Cc, _stream()),
+          "eeseg_bn_finalize")
+    return mean_invstd, scale_shift
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+    Cc = running_mean.numel()
+    ss = torch.empty((2, Cc), dtype=torch.float32, device=running_mean.device)
+    check(lib().eeseg_bn_eval_scale_shift(_p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(ss), Cc,
+                                          _stream()), "eeseg_bn_eval_scale_shift")
+    return ss
+
+
+def bn_apply(x, scale_shift, *, residual=None, relu=False, out=None, out_dtype=None):
+    _need_cuda(x)
+    rows, Cc, ldx = rows_ld(x)
+    od = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty(x.shape, dtype=od, device=x.device)
+    rows2, C2, ldy = rows_ld(out)
+    assert rows2 == rows and C2 == Cc
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+        _, _, ldres = rows_ld(residual)
+    check(lib().eeseg_bn_apply(_p(x), ldx, _p(scale_shift), _p(residual), ldres, _p(out), ldy, rows, Cc, int(relu),
+                               _dt(x), _dt(out), _stream()), "eeseg_bn_apply")
+    return out
+
+
+def channel_stats(x):
+    rows, Cc, ldx = rows_ld(x)
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    wsb = lib().eeseg_colreduce_workspace(rows, Cc)
+    ws = workspace(wsb, x.device)
+    check(lib().eeseg_channel_stats(_p(x), ldx, rows, Cc, _p(sums), _dt(x), _p(ws), ws.numel(), _stream()),
+          "eeseg_channel_stats")
+    return sums
+
+
+def colsum(x):
+    rows, Cc, ldx = rows_ld(x)
+    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
+    check(lib().eeseg_colsum(_p(x), ldx, rows, Cc, _p(out), _dt(x), _p(ws), ws.numel(), _stream()), "eeseg_colsum")
+    return out
+
+
+def bn_bwd_reduce(dy, y, x, mean_invstd, relu):
+    rows, Cc, lddy = rows_ld(dy)
+    _, _, ldx = rows_ld(x)
+    ldy = rows_ld(y)[2] if y is not None else 0
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
+    check(lib().eeseg_bn_bwd_reduce(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), rows, Cc, int(relu),
+                                    _p(sums), _dt(x), _p(ws), ws.numel(), _stream()), "eeseg_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(dy, y, x, mean_invstd, gamma, sums, count, relu, *, want_dres=False, dx=None):
+    rows, Cc, lddy = rows_ld(dy)
+    _, _, ldx = rows_ld(x)
+    ldy = rows_ld(y)[2] if y is not None else 0
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    lddx = rows_ld(dx)[2]
+    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
+    lddres = rows_ld(dres)[2] if dres is not None else 0
+    check(lib().eeseg_bn_bwd_apply(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), _p(gamma), _p(sums),
+                                   float(count), _p(dx), lddx, _p(dres), lddres, rows, Cc, int(relu), _dt(x),
+                                   _stream()), "eeseg_bn_bwd_apply")
+    return dx, dres
+
+
+def scale_act_bwd(dy, y, scale, relu, *, want_dres=False):
+    rows, Cc, lddy = rows_ld(dy)
+    ldy = rows_ld(y)[2] if y is not None else 0
+    dx = torch.empty(dy.shape, dtype=dy.dtype, device=dy.device)
+    dres = torch.empty(dy.shape, dtype=dy.dtype, device=dy.device) if want_dres else None
+    check(lib().eeseg_scale_act_bwd(_p(dy), lddy, _p(y), ldy, _p(scale), _p(dx), Cc, _p(dres), Cc if want_dres else 0,
+                                    rows, Cc, int(relu), _dt(dy), _stream()), "eeseg_scale_act_bwd")
+    return dx, dres
+
+
+# ------------------------------------------------------- pooling / misc ----
+def maxpool3x3s2(x):
+    N, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    check(lib().eeseg_maxpool3x3s2(_p(x), _p(y), N, H, W, Cc, Ho, Wo, _dt(x), _stream()), "eeseg_maxpool3x3s2")
+    return y
+
+
+def maxpool3x3s2_bwd(x, dy):
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    dx = torch.empty_like(x)
+    check(lib().eeseg_maxpool3x3s2_bwd(_p(x), _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, _dt(x), _stream()),
+          "eeseg_maxpool3x3s2_bwd")
+    return dx
+
+
+def sum_hw(x, scale=1.0):
+    """x [N,H,W,C] (slice ok) -> [N,C] = scale * sum over HW."""
+    N = x.shape[0]
+    rows, Cc, ldx = rows_ld(x)
+    y = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
+    check(lib().eeseg_sum_hw(_p(x), ldx, _p(y), N, rows // N, Cc, float(scale), _dt(x), _stream()), "eeseg_sum_hw")
+    return y
+
+
+def broadcast_hw(x, out, scale=1.0, accumulate=False):
+    """x [N,C] -> out [N,H,W,C] (slice ok) (+)= scale*x."""
+    N = out.shape[0]
+    rows, Cc, ldy = rows_ld(out)
+    assert x.shape == (N, Cc) and x.is_contiguous() and x.dtype == out.dtype
+    check(lib().eeseg_broadcast_hw(_p(x), _p(out), ldy, N, rows // N, Cc, float(scale), int(accumulate), _dt(x),
+                                   _stream()), "eeseg_broadcast_hw")
+    return out
+
+
+def dropout(x, p, seed):
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib().eeseg_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _dt(x), _stream()),
+          "eeseg_dropout")
+    return y
+
+
+def cast(x, dtype):
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().eeseg_cast(_p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream()), "eeseg_cast")
+    return y
+
+
+def add_inplace(y, x):
+    assert y.is_contiguous() and x.is_contiguous() and y.shape == x.shape and y.dtype == x.dtype
+    check(lib().eeseg_add_inplace(_p(y), _p(x), y.numel(), _dt(y), _stream()), "eeseg_add_inplace")
+    return y
+
+
+# ------------------------------------------------------ upsample / loss ----
+def _lr_dims(lr):
+    N, h, w, ldc = lr.shape
+    assert lr.is_contiguous() and lr.dtype == torch.float32
+    return N, h, w, ldc
+
+
+def upsample_bilinear_nchw(lr, C_, H, W, out=None):
+    N, h, w, ldc = _lr_dims(lr)
+    if out is None:
+        out = torch.empty((N, C_, H, W), dtype=torch.float32, device=lr.device)
+    assert out.is_contiguous() and out.shape == (N, C_, H, W)
+    check(lib().eeseg_upsample_bilinear_nchw(_p(lr), ldc, _p(out), N, C_, h, w, H, W, _stream()),
+          "eeseg_upsample_bilinear_nchw")
+    return out
+
+
+def upsample_bilinear_nchw_bwd(dout, h, w, ldc):
+    N, C_, H, W = dout.shape
+    assert dout.is_contiguous() and dout.dtype == torch.float32
+    dlr = torch.zeros((N, h, w, ldc), dtype=torch.float32, device=dout.device)
+    check(lib().eeseg_upsample_bilinear_nchw_bwd(_p(dout), _p(dlr), ldc, N, C_, h, w, H, W, _stream()),
+          "eeseg_upsample_bilinear_nchw_bwd")
+    return dlr
+
+
+def upsample_ce_fwd(lr, C_, target, H, W, ignore_index, accum):
+    """accum: float64[2] device tensor, (+)= (loss_sum, valid_count)."""
+    N, h, w, ldc = _lr_dims(lr)
+    assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
+    assert accum.dtype == torch.float64 and accum.numel() == 2
+    check(lib().eeseg_upsample_ce_fwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, int(ignore_index), _p(accum),
+                                      _stream()), "eeseg_upsample_ce_fwd")
+
+
+def upsample_ce_bwd(lr, C_, target, H, W, ignore_index, accum, gscale, dlr):
+    N, h, w, ldc = _lr_dims(lr)
+    assert dlr.shape == lr.shape and dlr.is_contiguous() and dlr.dtype == torch.float32
+    check(lib().eeseg_upsample_ce_bwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, int(ignore_index), _p(accum),
+                                      float(gscale), _p(dlr), _stream()), "eeseg_upsample_ce_bwd")
+
+
+def argmax_confusion(lr, C_, target, H, W, counts=None, want_pred=False):
+    N, h, w, ldc = _lr_dims(lr)
+    pred = torch.empty((N, H, W), dtype=torch.int64, device=lr.device) if want_pred else None
+    if target is not None:
+        assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
+        if counts is None:
+            counts = torch.zeros((3, C_), dtype=torch.int32, device=lr.device)
+    check(lib().eeseg_argmax_confusion(_p(lr), ldc, _p(target), N, C_, h, w, H, W, _p(counts), _p(pred), _stream()),
+          "eeseg_argmax_confusion")
+    return counts, pred
+
+
+def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1):
+    N, h, w, ldc = _lr_dims(lr)
+    ent = torch.empty((N,), dtype=torch.float32, device=lr.device)
+    flag = torch.empty((N,), dtype=torch.int32, device=lr.device)
+    wsb = lib().eeseg_entropy_gate_workspace(N, H, W)
+    ws = workspace(wsb, lr.device)
+    check(lib().eeseg_entropy_gate(_p(lr), ldc, N, C_, h, w, H, W, pool, pool_size, float(tau), _p(ent), _p(flag),
+                                   _p(ws), ws.numel(), _stream()), "eeseg_entropy_gate")
+    return ent, flag

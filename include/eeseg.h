@@ -1,0 +1,205 @@
+/* libeeseg - C ABI of the MI355X (gfx950) early-exit DeepLabV3 hot path.
+ *
+ * The reference (MateusGilbert/ee_semantic_segmentation) has NO FFI layer: every
+ * device op is reached implicitly through torch/torchvision.
+ * Each entry point below names the reference call site whose implicit device
+ * work it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *  - return 0 on success, <0 = EESEG_ERR_*; eeseg_last_error() gives the text
+ *    (thread local).
+ *  - the caller owns every buffer (device pointers, 16-byte aligned), passes
+ *    explicit shapes, and a hipStream_t as `void* stream`.  No hidden
+ *    allocation, no device synchronisation inside any call.
+ *  - activations are NHWC ("channels last"): x[n][h][w][c], c contiguous.
+ *    `dtype` selects the activation/weight element type of the call:
+ *    EESEG_F32 (exact fp32 MFMA, parity mode) or EESEG_BF16 (bf16 MFMA, fp32
+ *    accumulate, throughput mode).  Statistics, losses, counters, gradients of
+ *    weights and optimizer state are always fp32.
+ *  - conv weights are "KRSC": w[cout][r][s][cin], cin contiguous.
+ */
+#ifndef EESEG_H
+#define EESEG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { EESEG_F32 = 0, EESEG_BF16 = 1 };
+enum {
+    EESEG_OK = 0,
+    EESEG_ERR_ARG = -1,       /* bad shape / alignment / unsupported combination */
+    EESEG_ERR_HIP = -2,       /* HIP runtime error (launch failed, ...) */
+    EESEG_ERR_TOO_LARGE = -3  /* a buffer exceeds the 2 GiB buffer-descriptor range */
+};
+
+const char* eeseg_last_error(void);
+int eeseg_version(void);
+
+/* ---------------------------------------------------------------- conv ----
+ * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision
+ * Bottleneck / ASPP / DeepLabHead (from_deepv3_new.py:146-151 -> SURVEY 2.2).
+ *
+ * y[n,ho,wo,co] = sum_{r,s,ci} x[n, hi, wi, ci] * w[co,r,s,ci]
+ *   with hnum = ho*smul + off_h + r*tstep_h ; valid iff hnum % sdiv == 0 and
+ *   0 <= hnum/sdiv < Hin (same for w).  Forward conv: smul=stride, off=-pad,
+ *   tstep=dilation, sdiv=1.  Data-gradient: x:=dY, w:=transposed weights
+ *   [cin][r][s][cout], smul=1, off=+pad, tstep=-dilation, sdiv=stride.
+ * Epilogue (all optional): v = acc*scale[co] + shift[co]; v += residual;
+ *   v = relu(v); and per-channel partial sums of v, v^2 over each 128-pixel
+ *   tile -> stats[tile][2][Cout] (fp32) for train-mode BatchNorm.
+ * Cin must be a multiple of 64 (bf16) / 32 (f32).  ldy = output row stride in
+ * elements (>= Cout; lets a conv write into a channel slice of a wider tensor).
+ */
+typedef struct {
+    const void* x; const void* w; void* y;
+    const float* scale; const float* shift; const void* residual; float* stats;
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
+    int smul, off_h, off_w, tstep_h, tstep_w, sdiv;
+    int ldy, ldres, relu, dtype;
+} eeseg_conv_args;
+int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */
+int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream);
+
+/* Weight gradient: dw[co][r][s][ci] (+)= sum_{n,ho,wo} dy[n,ho,wo,co]*x[n,hi,wi,ci]
+ * (forward geometry).  dw is fp32 KRSC; accumulate=0 zero-fills it first.
+ * Replaces the conv weight-grad inside `l.mean().backward()` (train_funcs.py:26). */
+typedef struct {
+    const void* x; const void* dy; float* dw;
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
+    int stride, pad, dil, dtype, accumulate;
+} eeseg_wgrad_args;
+int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
+
+/* fp32 master weight -> compute-dtype KRSC (`w_fwd` [Cout_pad][R][S][Cin], may be
+ * NULL) and transposed CRSK (`w_bwd` [Cin][R][S][Cout_pad], may be NULL; the
+ * "weights" of the data-gradient call).  Rows co >= Cout are zero filled.
+ * src_krsc: 1 = src is [co][r][s][ci] (torch channels_last parameter), 0 = torch
+ * default [co][ci][r][s]. */
+int eeseg_pack_weight(const float* src, void* w_fwd, void* w_bwd, int Cout, int Cout_pad, int Cin, int R, int S,
+                      int src_krsc, int dtype, void* stream);
+/* fp32 [rows][cols] (row stride ld_src) -> dtype [rows_pad][cols_pad], zero padded
+ * (stem weight [64][147] -> [64][192] for the im2col GEMM). */
+int eeseg_pack_matrix(const float* src, int rows, int cols, int ld_src, void* dst, int rows_pad, int cols_pad,
+                      int dtype, void* stream);
+
+/* Stem: NCHW fp32 image -> im2col rows [N*Ho*Wo][Kpad] (k = (r*S+s)*C+ci, zero
+ * padded to Kpad) so the 7x7/s2 stem conv (Cin=3) runs as a GEMM.
+ * Replaces conv1 of the torchvision ResNet stem (from_deepv3_new.py:77-79). */
+int eeseg_im2col_nchw(const float* x, void* col, int N, int C, int H, int W, int R, int S, int stride,
+                      int pad, int Ho, int Wo, int Kpad, int dtype, void* stream);
+
+/* ----------------------------------------------------------- batchnorm ----
+ * Train-mode BatchNorm2d split as: conv epilogue partial sums -> reduce ->
+ * (all-reduce under SyncBN) -> finalize -> apply(+residual, ReLU).  Replaces
+ * F.batch_norm / relu / `out += identity` in torchvision Bottleneck / ASPP
+ * (SURVEY 2.2).  count = N*H*W (global count under SyncBN).  mean_invstd[2][C]
+ * is saved for backward; scale_shift[2][C] feeds eeseg_bn_apply.  Running stats
+ * are updated with `momentum` and the unbiased variance when running_mean != NULL.
+ * Column reductions over more than one row block need a workspace of
+ * eeseg_colreduce_workspace(rows, C) bytes. */
+int64_t eeseg_colreduce_workspace(int64_t rows, int C);
+/* partials[tiles][KC] -> sums[KC] (fixed order, double accumulation) */
+int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* stream);
+int eeseg_bn_finalize(const float* sums /*[2][C]*/, double count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean_invstd, float* scale_shift, int C, void* stream);
+/* eval mode: scale/shift from running stats */
+int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                              const float* running_var, float eps, float* scale_shift, int C, void* stream);
+/* y = act(x*scale[c] + shift[c] (+ residual)); x rows have stride ldx, y rows ldy
+ * (elements).  out_dtype may differ from in_dtype (bf16 -> f32 before the
+ * classifier).  rows = N*H*W. */
+int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
+                   void* y, int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype, void* stream);
+/* per-channel sums of x and x^2 over rows (tensors that did not come out of the
+ * conv epilogue, e.g. the pooled ASPP branch): sums[2][C] */
+int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+/* backward, step 1: g = dy * (y > 0 if relu); sums[0][c] = sum g, sums[1][c] = sum g*xhat */
+int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                        const float* mean_invstd, int64_t rows, int C, int relu, float* sums, int dtype,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+/* backward, step 2: dx = gamma*invstd*(g - sums0/count - xhat*sums1/count);
+ * dres (optional) = g.  dgamma = sums1, dbeta = sums0 (taken by the host). */
+int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                       const float* mean_invstd, const float* gamma, const float* sums, double count,
+                       void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
+                       void* stream);
+/* frozen-BN / plain backward of y = act(x*scale+shift): dx = g*scale, dres = g */
+int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int ldy, const float* scale,
+                        void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
+                        void* stream);
+
+/* --------------------------------------------------- pooling / misc ------- */
+/* 3x3 stride-2 pad-1 max pool (ResNet stem, from_deepv3_new.py:77-79); backward
+ * routes each window's gradient to its FIRST maximum (torch CPU tie rule). */
+int eeseg_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype, void* stream);
+int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo,
+                           int dtype, void* stream);
+/* per-image column sum: y[n][c] = scale * sum_hw x[n][hw][c] (ASPPPooling's
+ * AdaptiveAvgPool2d(1) with scale = 1/HW; also the backward of the broadcast) */
+int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype, void* stream);
+/* y[n][hw][c] (+)= scale * x[n][c] into a channel slice of row stride ldy
+ * (ASPPPooling's bilinear upsample from 1x1 is a broadcast; with scale = 1/HW
+ * and accumulate = 1 it is the backward of the average pool) */
+int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW, int C, float scale, int accumulate,
+                       int dtype, void* stream);
+/* Dropout(p) with a counter-based hash RNG: keep iff hash(seed, index) >= p;
+ * kept values are scaled by 1/(1-p).  Backward = the same call on dy. */
+int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, int64_t n, void* stream);
+/* y[i] += x[i] (gradient accumulation at residual joins) */
+int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream);
+/* per-column sum of a [rows][C] matrix -> out[C] fp32 (bias gradient) */
+int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* out, int dtype, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------ upsample / losses -------
+ * logits_lr: [N,h,w,ldc] fp32 NHWC low-resolution logits of ONE exit (C <= 32
+ * valid channels, ldc >= C). */
+/* out: [N,C,H,W] fp32 NCHW.  Replaces F.interpolate(bilinear,
+ * align_corners=False) at from_deepv3_new.py:149,152. */
+int eeseg_upsample_bilinear_nchw(const float* logits_lr, int ldc, float* out, int N, int C, int h, int w,
+                                 int H, int W, void* stream);
+int eeseg_upsample_bilinear_nchw_bwd(const float* dout, float* dlogits_lr, int ldc, int N, int C, int h, int w,
+                                     int H, int W, void* stream);
+/* Fused upsample + per-pixel cross entropy for one exit
+ * (my_pixelwise_xentropy.py:11-14,36-38: CrossEntropyLoss(mean, ignore_index)).
+ * accum (double[2], device): [0] += sum of -log p[target] over valid pixels,
+ * [1] += #valid.  Labels outside [0,C) are treated as ignored. */
+int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
+                          int H, int W, int64_t ignore_index, double* accum /*[2]*/, void* stream);
+/* dlogits_lr += gscale/accum[1] * d(sum CE)/d(logits_lr)  (reads the valid count
+ * from device memory: no host sync).  The caller zeroes dlogits_lr. */
+int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
+                          int H, int W, int64_t ignore_index, const double* accum, float gscale,
+                          float* dlogits_lr, void* stream);
+/* Fused upsample + argmax + TP/FP/FN (seg_metrics.py:13-28 + compute_mIoU.py:16-27):
+ * counts[3][C] int32 (+= per call, exact); void pixels (label outside [0,C))
+ * count as FP of the predicted class (B-9).  pred (optional) receives the argmax
+ * mask [N,H,W] int64; target may be NULL when only pred is wanted. */
+int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
+                           int H, int W, int32_t* counts, int64_t* pred, void* stream);
+/* Fused upsample + softmax + normalised entropy (+ s x s max/min block pool) +
+ * mean per image (eval_br_ent.py:19-36).  entropy_out[N] fp32; exit_flag[N]
+ * int32 = (entropy < tau) stays on device (eval_br_ent.py:60, ee_dnn_op_ne.py:81).
+ * pool: 0 none, 1 max, 2 min. */
+int64_t eeseg_entropy_gate_workspace(int N, int H, int W);
+int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W, int pool,
+                       int pool_size, float tau, float* entropy_out, int32_t* exit_flag, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------- SGD ------
+ * torch.optim.SGD(momentum, weight_decay) step, multi-tensor
+ * (deepv3_funcs.py:99; train_funcs.py:27).  ptrs: device array of
+ * {param, grad, momentum_buf} triples; sizes: device array of element counts;
+ * lrs: device array of per-tensor learning rates.  first_step=1 initialises
+ * the momentum buffer with the gradient (torch semantics). */
+int eeseg_sgd_step(void* const* param_grad_buf /*[n][3]*/, const int64_t* sizes, const float* lrs, int n,
+                   float momentum, float weight_decay, float grad_scale, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

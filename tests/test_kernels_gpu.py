@@ -1,0 +1,349 @@
+"""GPU parity tests of every libeeseg kernel (through the C ABI) against the CPU
+oracle: torch CPU fp32 ops (what the reference reaches through torchvision) and
+the golden vectors generated from the importable reference files.
+
+Tolerances: fp32 mode -> 1e-4 relative to the result scale (summation order only);
+bf16 mode -> inputs are rounded to bf16 first, 2^-7 relative (bf16 output rounding).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from ee_semantic_segmentation_amd import kernels as K
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "losses_seed*.npz")))
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 1.6e-2
+
+
+def rnd(dtype, *shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(*shape, generator=g) * scale
+    return t.to(dtype).float()     # value exactly representable in `dtype`
+
+
+def close(got, want, rel, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-12
+    err = (got - want).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
+
+
+def nhwc(t):   # NCHW cpu -> NHWC
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 9, 7, 64, 128, 1, 1, 0, 1),
+    (3, 17, 13, 128, 64, 1, 1, 0, 1),
+    (2, 13, 11, 64, 128, 3, 1, 1, 1),
+    (2, 13, 11, 64, 256, 3, 1, 2, 2),
+    (1, 17, 17, 128, 256, 3, 1, 12, 12),     # atrous: whole taps fall outside (tap skipping)
+    (2, 15, 14, 64, 128, 3, 2, 1, 1),        # strided
+    (2, 12, 12, 128, 256, 1, 2, 0, 1),       # strided 1x1 (downsample)
+    (2, 10, 9, 256, 32, 1, 1, 0, 1),         # narrow classifier-like output
+    (1, 40, 40, 192, 64, 1, 1, 0, 1),        # stem-GEMM-like K
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    N, H, W, Cin, Cout, k, s, p, d = case
+    x = rnd(dtype, N, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p, dilation=d)
+    gy = rnd(dtype, *y.shape, seed=3)
+    y.backward(gy)
+
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wf, wb = K.pack_weight(w.detach().to(DEV), dtype)
+    close(wf.permute(0, 3, 1, 2), w, 1e-7, "pack fwd")
+    close(wb.permute(3, 0, 1, 2), w, 1e-7, "pack bwd")
+    yd, part = K.conv_fwd(xd, wf, s, p, d, want_stats=True)
+    close(nchw(yd), y, tol(dtype), "conv fwd")
+    # BN partial sums from the epilogue (computed on the stored, rounded output)
+    ys = yd.float().reshape(-1, Cout)
+    sums = K.reduce_partials(part)
+    close(sums[0], ys.sum(0), 1e-4, "stats sum")
+    close(sums[1], (ys * ys).sum(0), 1e-4, "stats sumsq")
+
+    gyd = nhwc(gy).to(DEV, dtype)
+    dx = K.conv_dgrad(gyd, wb, (H, W), s, p, d)
+    close(nchw(dx), x.grad, tol(dtype), "conv dgrad")
+    dw = K.conv_wgrad(xd, gyd, k, k, s, p, d)
+    close(dw.permute(0, 3, 1, 2), w.grad, 2e-4 if dtype == torch.float32 else 4e-3, "conv wgrad")
+    # accumulation variants
+    dx2 = K.conv_dgrad(gyd, wb, (H, W), s, p, d, accumulate_into=dx.clone())
+    close(nchw(dx2), 2 * x.grad, 2 * tol(dtype), "conv dgrad accumulate")
+    dw2 = K.conv_wgrad(xd, gyd, k, k, s, p, d, out=dw.clone(), accumulate=True)
+    close(dw2.permute(0, 3, 1, 2), 2 * w.grad, 2e-4 if dtype == torch.float32 else 4e-3, "conv wgrad accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_epilogue_and_slice_output(dtype):
+    N, H, W, Cin, Cout = 2, 11, 9, 64, 128
+    x = rnd(dtype, N, Cin, H, W, seed=4)
+    w = rnd(dtype, Cout, Cin, 3, 3, seed=5, scale=0.05)
+    res = rnd(dtype, N, Cout, H, W, seed=6)
+    scale = torch.rand(Cout) + 0.5
+    shift = torch.randn(Cout)
+    want = F.relu(F.conv2d(x, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    wf, _ = K.pack_weight(w.to(DEV), dtype, want_bwd=False)
+    wide = torch.zeros(N, H, W, 3 * Cout, dtype=dtype, device=DEV)
+    out = wide[..., Cout:2 * Cout]
+    K.conv_fwd(nhwc(x).to(DEV, dtype), wf, 1, 1, 1, scale=scale.to(DEV), shift=shift.to(DEV),
+               residual=nhwc(res).to(DEV, dtype), relu=True, out=out)
+    close(nchw(out), want, tol(dtype) * 2, "fused epilogue")
+    assert wide[..., :Cout].abs().max().item() == 0 and wide[..., 2 * Cout:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_stem_im2col_gemm(dtype):
+    N, H, W = 2, 33, 29
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(7))
+    w = rnd(dtype, 64, 3, 7, 7, seed=8, scale=0.1)
+    want = F.conv2d(x.to(dtype).float(), w, stride=2, padding=3)
+    col = K.im2col_nchw(x.to(DEV), 7, 7, 2, 3, 192, dtype)
+    wk = w.permute(0, 2, 3, 1).reshape(64, 147).contiguous()
+    wm = K.pack_matrix(wk.to(DEV), 64, 192, dtype).view(64, 1, 1, 192)
+    y, _ = K.conv_fwd(col, wm)
+    close(nchw(y), want, tol(dtype), "stem conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_train_fwd_bwd(dtype, relu, use_res):
+    N, H, W, Cc = 3, 23, 19, 128
+    x = rnd(dtype, N, Cc, H, W, seed=9, scale=2.0).add_(0.3).to(dtype).float().requires_grad_(True)
+    res = rnd(dtype, N, Cc, H, W, seed=10).requires_grad_(True)
+    gamma = (torch.rand(Cc) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cc).requires_grad_(True)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    y = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if use_res:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    gy = rnd(dtype, *y.shape, seed=11)
+    y.backward(gy)
+
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    sums = K.channel_stats(xd)
+    rmd, rvd = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    cnt = N * H * W
+    mi, ss = K.bn_finalize(sums, cnt, gamma.detach().to(DEV), beta.detach().to(DEV), 1e-5, 0.1, rmd, rvd)
+    close(rmd, rm, 1e-5, "running mean")
+    close(rvd, rv, 1e-5, "running var")
+    resd = nhwc(res.detach()).to(DEV, dtype) if use_res else None
+    yd = K.bn_apply(xd, ss, residual=resd, relu=relu)
+    close(nchw(yd), y, tol(dtype), "bn fwd")
+    gyd = nhwc(gy).to(DEV, dtype)
+    bs = K.bn_bwd_reduce(gyd, yd if relu else None, xd, mi, relu)
+    close(bs[0], beta.grad, 2e-4 if dtype == torch.float32 else 2e-2, "dbeta")
+    close(bs[1], gamma.grad, 2e-4 if dtype == torch.float32 else 2e-2, "dgamma")
+    dx, dres = K.bn_bwd_apply(gyd, yd if relu else None, xd, mi, gamma.detach().to(DEV), bs, cnt, relu,
+                              want_dres=use_res)
+    close(nchw(dx), x.grad, 3e-4 if dtype == torch.float32 else 3e-2, "bn dx")
+    if use_res:
+        close(nchw(dres), res.grad, tol(dtype), "bn dres")
+
+
+def test_bn_eval_and_frozen_bwd():
+    Cc = 64
+    g, b, rm, rv = torch.rand(Cc) + 0.5, torch.randn(Cc), torch.randn(Cc), torch.rand(Cc) + 0.5
+    ss = K.bn_eval_scale_shift(g.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5)
+    x = torch.randn(2, Cc, 5, 6, requires_grad=True)
+    y = F.relu(F.batch_norm(x, rm, rv, g, b, training=False, eps=1e-5))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yd = K.bn_apply(nhwc(x.detach()).to(DEV), ss, relu=True)
+    close(nchw(yd), y, 1e-5, "bn eval")
+    dx, _ = K.scale_act_bwd(nhwc(gy).to(DEV), yd, ss[0].contiguous(), True)
+    close(nchw(dx), x.grad, 1e-5, "frozen bn bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_maxpool_fwd_bwd_with_ties(dtype):
+    N, Cc, H, W = 2, 64, 17, 21
+    x = F.relu(rnd(dtype, N, Cc, H, W, seed=12)).requires_grad_(True)    # many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = rnd(dtype, *y.shape, seed=13)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    yd = K.maxpool3x3s2(xd)
+    close(nchw(yd), y, 0.0 + 1e-7, "maxpool fwd")
+    dx = K.maxpool3x3s2_bwd(xd, nhwc(gy).to(DEV, dtype))
+    close(nchw(dx), x.grad, tol(dtype), "maxpool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_gap_broadcast_dropout_cast_add(dtype):
+    N, H, W, Cc = 3, 9, 11, 256
+    wide = rnd(dtype, N, H, W, 2 * Cc, seed=14).to(DEV, dtype)
+    xs = wide[..., Cc:]
+    got = K.sum_hw(xs, 1.0 / (H * W))
+    close(got, xs.float().mean(dim=(1, 2)), tol(dtype), "gap")
+    out = torch.zeros(N, H, W, 3 * Cc, dtype=dtype, device=DEV)
+    K.broadcast_hw(got, out[..., Cc:2 * Cc])
+    close(out[..., Cc:2 * Cc], got.float().view(N, 1, 1, Cc).expand(N, H, W, Cc), 1e-6, "broadcast")
+    K.broadcast_hw(got, out[..., Cc:2 * Cc], scale=0.5, accumulate=True)
+    close(out[..., Cc:2 * Cc], 1.5 * got.float().view(N, 1, 1, Cc).expand(N, H, W, Cc), tol(dtype), "broadcast acc")
+    assert out[..., :Cc].abs().max().item() == 0
+    # dropout
+    x = torch.ones(4, 64, 64, 16, dtype=dtype, device=DEV)
+    d1, d2, d3 = K.dropout(x, 0.5, 123), K.dropout(x, 0.5, 123), K.dropout(x, 0.5, 124)
+    assert torch.equal(d1, d2) and not torch.equal(d1, d3)
+    keep = (d1 != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01 and set(d1.float().unique().tolist()) == {0.0, 2.0}
+    # cast / add / colsum
+    f = torch.randn(1000, 64, device=DEV)
+    close(K.cast(f, torch.bfloat16), f.bfloat16(), 1e-6, "cast")
+    a, b = wide.clone(), wide.clone()
+    K.add_inplace(a, b)
+    close(a, 2 * wide.float(), tol(dtype), "add")
+    close(K.colsum(xs), xs.float().reshape(-1, Cc).sum(0), 1e-3 if dtype == torch.float32 else 1e-2, "colsum")
+
+
+def _lr_from_nchw(y, ldc=32):
+    """[N,C,H,W] cpu -> device NHWC [N,H,W,ldc] fp32 zero padded."""
+    N, Cc, H, W = y.shape
+    lr = torch.zeros(N, H, W, ldc)
+    lr[..., :Cc] = y.permute(0, 2, 3, 1)
+    return lr.to(DEV)
+
+
+@pytest.mark.parametrize("hw,HW", [((9, 7), (65, 50)), ((17, 17), (129, 129)), ((5, 8), (5, 8)), ((12, 10), (7, 9))])
+def test_upsample_fwd_bwd(hw, HW):
+    h, w = hw
+    H, W = HW
+    N, Cc = 2, 21
+    y = torch.randn(N, Cc, h, w, generator=torch.Generator().manual_seed(15)).requires_grad_(True)
+    up = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=False)
+    g = torch.randn(up.shape, generator=torch.Generator().manual_seed(16))
+    up.backward(g)
+    lr = _lr_from_nchw(y.detach())
+    got = K.upsample_bilinear_nchw(lr, Cc, H, W)
+    close(got, up, 2e-6, "upsample")
+    dlr = K.upsample_bilinear_nchw_bwd(g.to(DEV), h, w, 32)
+    close(dlr[..., :Cc].permute(0, 3, 1, 2), y.grad, 1e-5, "upsample bwd")
+
+
+@pytest.mark.parametrize("hw,HW,Cc", [((9, 7), (65, 50), 21), ((17, 17), (129, 129), 19), ((6, 5), (6, 5), 5)])
+def test_upsample_ce_fwd_bwd(hw, HW, Cc):
+    h, w = hw
+    H, W = HW
+    N = 3
+    gen = torch.Generator().manual_seed(17)
+    y = (torch.randn(N, Cc, h, w, generator=gen) * 2).requires_grad_(True)
+    t = torch.randint(0, Cc + 1, (N, H, W), generator=gen)
+    up = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=False)
+    loss = F.cross_entropy(up, t, ignore_index=Cc)
+    (loss * 0.7).backward()
+    lr = _lr_from_nchw(y.detach())
+    acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    td = t.to(DEV)
+    K.upsample_ce_fwd(lr, Cc, td, H, W, Cc, acc)
+    a = acc.cpu()
+    assert a[1].item() == (t != Cc).sum().item()
+    assert abs(a[0].item() / a[1].item() - loss.item()) < 2e-6 * max(1, abs(loss.item()))
+    dlr = torch.zeros_like(lr)
+    K.upsample_ce_bwd(lr, Cc, td, H, W, Cc, acc, 0.7, dlr)
+    close(dlr[..., :Cc].permute(0, 3, 1, 2), y.grad, 2e-5, "ce bwd")
+    assert dlr[..., Cc:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_reference_golden_through_hip(path):
+    """The golden vectors were produced by the reference's own loss / metric code;
+    with h==H, w==W the fused kernels see an identity upsample."""
+    g = np.load(path)
+    y, t, void = torch.from_numpy(g["y"]), torch.from_numpy(g["t"]), int(g["void"])
+    E, B, Cc, H, W = y.shape
+    td = t.squeeze(1).contiguous().to(DEV)
+    total = 0.0
+    for e in range(E):
+        lr = _lr_from_nchw(y[e])
+        acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+        K.upsample_ce_fwd(lr, Cc, td, H, W, void, acc)
+        a = acc.cpu()
+        total += a[0].item() / a[1].item()
+        dlr = torch.zeros_like(lr)
+        K.upsample_ce_bwd(lr, Cc, td, H, W, void, acc, 1.0, dlr)
+        np.testing.assert_allclose(dlr[..., :Cc].permute(0, 3, 1, 2).cpu().numpy(), g["ce_sum_grad"][e],
+                                   rtol=2e-4, atol=2e-7)
+        # mIoU counters (compute_mIoU.py) - exact integers
+        counts, pred = K.argmax_confusion(lr, Cc, td, H, W, want_pred=True)
+        assert torch.equal(pred.cpu(), y[e].argmax(1))
+        if e == 0:
+            np.testing.assert_array_equal(counts.cpu().numpy().astype(np.float32), g["acc0"])
+        c = counts.cpu().numpy().astype(np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            miou = float((c[0] / c.sum(0)).sum() / Cc)
+        want = float(g["miou"][e])
+        assert (np.isnan(miou) and np.isnan(want)) or abs(miou - want) < 1e-6
+        # entropy gate (eval_br_ent.py:19-36)
+        ent, flag = K.entropy_gate(lr * float(g["gate_scale"]), Cc, H, W, tau=0.5)
+        np.testing.assert_allclose(ent.cpu().numpy(), g["entropy"][e], rtol=0, atol=3e-6)
+        assert flag.cpu().tolist() == [int(v < 0.5) for v in ent.cpu().tolist()]
+    assert abs(total - float(g["ce_sum"])) < 2e-6 * max(1.0, abs(total))
+
+
+def test_entropy_gate_pooling_matches_oracle():
+    from oracle import metrics_ref
+    N, Cc, h, w, H, W = 2, 19, 8, 9, 33, 38
+    y = torch.randn(N, Cc, h, w, generator=torch.Generator().manual_seed(18)) * 3
+    up = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=False)
+    lr = _lr_from_nchw(y)
+    for pool, s in [(0, 1), (1, 4), (2, 4), (1, 5), (2, 3)]:
+        ent, _ = K.entropy_gate(lr, Cc, H, W, tau=0.3, pool=pool, pool_size=s)
+        for n in range(N):
+            p = metrics_ref.softmax_np(up[n].numpy(), axis=0)
+            want = metrics_ref.img_norm_entropy(p, Cc, pool_min=(pool == 2), s=s if pool else 1)
+            assert abs(ent[n].item() - want) < 5e-6, (pool, s, n)
+
+
+def test_sgd_step_matches_torch():
+    from ee_semantic_segmentation_amd import _lib
+    import ctypes as C
+    shapes = [(64, 3, 7, 7), (1000,), (37,), (256, 256, 3, 3)]
+    ps = [torch.randn(s) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.SGD([{"params": ref[:2], "lr": 0.01}, {"params": ref[2:], "lr": 0.02}], lr=0.01,
+                          momentum=0.9, weight_decay=5e-4)
+    dev = [p.clone().to(DEV) for p in ps]
+    bufs = [torch.zeros_like(p) for p in dev]
+    lrs = torch.tensor([0.01, 0.01, 0.02, 0.02], device=DEV)
+    sizes = torch.tensor([p.numel() for p in dev], dtype=torch.int64, device=DEV)
+    for step in range(3):
+        grads = [torch.randn(s, generator=torch.Generator().manual_seed(100 + step)) for s in shapes]
+        for r, g in zip(ref, grads):
+            r.grad = g.clone()
+        opt.step()
+        gd = [g.to(DEV) for g in grads]
+        ptrs = torch.tensor([[p.data_ptr(), g.data_ptr(), b.data_ptr()] for p, g, b in zip(dev, gd, bufs)],
+                            dtype=torch.int64, device=DEV)
+        _lib.check(_lib.lib().eeseg_sgd_step(C.c_void_p(ptrs.data_ptr()), C.c_void_p(sizes.data_ptr()),
+                                             C.c_void_p(lrs.data_ptr()), len(dev), 0.9, 5e-4, 1.0, int(step == 0),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sgd")
+        torch.cuda.synchronize()
+        for p, r in zip(dev, ref):
+            close(p, r, 1e-6, f"sgd step {step}")
