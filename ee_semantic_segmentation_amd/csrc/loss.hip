@@ -158,13 +158,13 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __res
                                                               const int64_t* __restrict__ target, int N, int C, int h,
                                                               int w, int H, int W, long long ignore_index,
                                                               const double* __restrict__ accum, float gscale,
-                                                              float* dlr) {
+                                                              const float* __restrict__ gscale_dev, float* dlr) {
     const int lane32 = threadIdx.x & 31;
     const int half = threadIdx.x >> 5;
     const float sh = (float)h / (float)H, sw = (float)w / (float)W;
     const double cnt = accum[1];
     if (!(cnt > 0.0)) return;
-    const float g = (float)((double)gscale / cnt);
+    const float g = (float)((double)gscale * (gscale_dev ? (double)gscale_dev[0] : 1.0) / cnt);
     const bool active = lane32 < C;
     const long long total = (long long)N * H * w;
     for (long long it = (long long)blockIdx.x * 8 + half; it < total; it += (long long)gridDim.x * 8) {
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __res
         // span of x with floor(src(x)) == x0 : invert src = sw*(x+0.5)-0.5 conservatively, then test
         int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
         int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
-        xa = max(xa, 0); xb = min(xb, W - 1);
+        xa = (x0 == 0) ? 0 : max(xa, 0);      // sources clamped at 0 all land in column 0
+        xb = min(xb, W - 1);
         const Src sy = src_index(y, sh, h);
         float a0 = 0.f, a1 = 0.f;
         for (int x = xa; x <= xb; ++x) {
@@ -384,11 +385,12 @@ extern "C" int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int6
 
 extern "C" int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
                                      int H, int W, int64_t ignore_index, const double* accum, float gscale,
-                                     float* dlogits_lr, void* stream) {
+                                     const float* gscale_dev, float* dlogits_lr, void* stream) {
     CHECK_LR("upsample_ce_bwd");
     EESEG_CHECK(target && accum && dlogits_lr, EESEG_ERR_ARG, "upsample_ce_bwd: null pointer");
     hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3(px_grid((long long)N * H * w)), dim3(256), 0, (hipStream_t)stream,
-                       logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum, gscale, dlogits_lr);
+                       logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum, gscale, gscale_dev,
+                       dlogits_lr);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -1,0 +1,297 @@
+"""Explicit forward / backward of the DeepLabV3 building blocks over libeeseg.
+
+Nothing here is traced or compiled: each function issues the HIP kernels of one
+fused layer group on the current stream and returns the tensors backward needs.
+The autograd Functions in ``nn_modules`` wrap whole blocks (stem, bottleneck,
+head) so gradient accumulation at residual / ASPP joins also happens inside
+libeeseg kernels (data-gradient calls accumulate in place through the conv
+epilogue's residual input).
+
+Reference ops restated: torchvision Bottleneck / ASPP /
+DeepLabHead reached from from_deepv3_new.py:146-151.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+CPAD = 32           # classifier output channels are padded to one 128-byte row
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    """Called by optimizers that update parameters through raw pointers."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
+class Config:
+    """Run-time switches shared by every module of one network."""
+
+    def __init__(self):
+        self.compute_dtype = torch.float32   # torch.bfloat16 = throughput mode
+        self.sync_bn = False                 # all-reduce BN statistics over the process group
+        self.group = None
+        self.dropout_seed = 0x5EED
+        self._drop_calls = 0
+
+    def world(self):
+        return dist.get_world_size(self.group) if (self.sync_bn and dist.is_initialized()) else 1
+
+    def next_seed(self):
+        self._drop_calls += 1
+        return (self.dropout_seed * 0x9E3779B97F4A7C15 + self._drop_calls) & (2 ** 63 - 1)
+
+
+def packed(conv, dtype, cout_pad=None):
+    """(w_fwd KRSC, w_bwd CRSK) of a conv module in `dtype`, cached per weight version."""
+    w = conv.weight
+    key = (w._version, _WEIGHTS_EPOCH[0], dtype, w.data_ptr(), cout_pad)
+    cache = conv.__dict__.get("_eeseg_pack")
+    if cache is None or cache[0] != key:
+        wf, wb = K.pack_weight(w.detach(), dtype, cout_pad)
+        cache = (key, wf, wb)
+        conv.__dict__["_eeseg_pack"] = cache
+    return cache[1], cache[2]
+
+
+def _geom(conv):
+    return conv.stride[0], conv.padding[0], conv.dilation[0]
+
+
+def _allreduce(cfg, t):
+    if cfg.world() > 1:
+        dist.all_reduce(t, group=cfg.group)
+    return t
+
+
+# ------------------------------------------------------- conv + BN (+ReLU) ----
+def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False):
+    """Train-mode conv -> BN(batch stats) -> (+residual) -> ReLU.  Returns (y, state)."""
+    if x_is_col:      # stem GEMM: x is the im2col matrix, weight is the padded [Cout,1,1,Kpad] matrix
+        wf = packed_stem(conv, x.dtype, x.shape[-1])
+        c, part = K.conv_fwd(x, wf, want_stats=True)
+    else:
+        wf, _ = packed(conv, x.dtype)
+        s, p, d = _geom(conv)
+        c, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
+    sums = K.reduce_partials(part)
+    count = c.numel() // c.shape[-1]
+    if cfg.world() > 1:
+        _allreduce(cfg, sums)
+        count *= cfg.world()
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+    bn._pending_batches += 1
+    y = K.bn_apply(c, ss, residual=residual, relu=relu, out=out)
+    return y, (x, c, y, mi, count, relu)
+
+
+def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):
+    """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta)."""
+    x, c, y, mi, count, relu = st
+    sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu)
+    dbeta, dgamma = sums[0], sums[1]
+    if cfg.world() > 1:
+        dbeta, dgamma = dbeta.clone(), dgamma.clone()      # parameter grads stay local (DP averages them)
+        _allreduce(cfg, sums)
+    dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres)
+    if x_is_col:
+        dw = K.conv_wgrad(x, dc, 1, 1)
+        cout, _, r, s_ = conv.weight.shape
+        cin = conv.weight.shape[1]
+        dwp = dw.view(cout, -1)[:, :r * s_ * cin].reshape(cout, r, s_, cin).permute(0, 3, 1, 2)
+        return None, dres, dwp, dgamma, dbeta
+    s, p, d = _geom(conv)
+    R, S = conv.weight.shape[2], conv.weight.shape[3]
+    dw = K.conv_wgrad(x, dc, R, S, s, p, d)
+    dx = None
+    if need_dx:
+        _, wb = packed(conv, dc.dtype)
+        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+    return dx, dres, dw.permute(0, 3, 1, 2), dgamma, dbeta
+
+
+def conv_bn_eval(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False):
+    """Eval-mode conv with BN folded into the conv epilogue (one kernel)."""
+    ss = K.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    if x_is_col:
+        wf = packed_stem(conv, x.dtype, x.shape[-1])
+        y, _ = K.conv_fwd(x, wf, scale=ss[0], shift=ss[1], residual=residual, relu=relu, out=out)
+    else:
+        wf, _ = packed(conv, x.dtype)
+        s, p, d = _geom(conv)
+        y, _ = K.conv_fwd(x, wf, s, p, d, scale=ss[0], shift=ss[1], residual=residual, relu=relu, out=out)
+    return y
+
+
+def packed_stem(conv, dtype, kpad):
+    w = conv.weight
+    key = (w._version, _WEIGHTS_EPOCH[0], dtype, w.data_ptr(), kpad, "stem")
+    cache = conv.__dict__.get("_eeseg_pack_stem")
+    if cache is None or cache[0] != key:
+        cout, cin, r, s = w.shape
+        wk = w.detach().permute(0, 2, 3, 1).reshape(cout, r * s * cin)    # KRSC rows (view when channels_last)
+        if not wk.is_contiguous():
+            wk = wk.contiguous()
+        wm = K.pack_matrix(wk, cout, kpad, dtype).view(cout, 1, 1, kpad)
+        cache = (key, wm)
+        conv.__dict__["_eeseg_pack_stem"] = cache
+    return cache[1]
+
+
+STEM_KPAD = 192     # 7*7*3 = 147 -> multiple of 64
+
+
+# ------------------------------------------------------------------- stem ----
+def stem_fwd(cfg, img, conv, bn, train):
+    """img [N,3,H,W] fp32 NCHW -> [N,H/4,W/4,64] NHWC in compute dtype."""
+    if not img.is_contiguous():
+        img = img.contiguous()
+    if img.dtype != torch.float32:
+        img = img.float()
+    r = conv.weight.shape[2]
+    col = K.im2col_nchw(img, r, r, conv.stride[0], conv.padding[0], STEM_KPAD, cfg.compute_dtype)
+    if train:
+        y, st = conv_bn_fwd(cfg, col, conv, bn, True, x_is_col=True)
+    else:
+        y, st = conv_bn_eval(cfg, col, conv, bn, True, x_is_col=True), None
+    p = K.maxpool3x3s2(y)
+    return p, (st, y)
+
+
+def stem_bwd(cfg, state, dp, conv, bn):
+    st, y = state
+    dy = K.maxpool3x3s2_bwd(y, dp)
+    _, _, dw, dg, db = conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=False, x_is_col=True)
+    return dw, dg, db
+
+
+# ------------------------------------------------------------- bottleneck ----
+def bottleneck_fwd(cfg, x, blk, train):
+    ds = blk.downsample
+    if not train:
+        y1 = conv_bn_eval(cfg, x, blk.conv1, blk.bn1, True)
+        y2 = conv_bn_eval(cfg, y1, blk.conv2, blk.bn2, True)
+        idn = conv_bn_eval(cfg, x, ds[0], ds[1], False) if ds is not None else x
+        return conv_bn_eval(cfg, y2, blk.conv3, blk.bn3, True, residual=idn), None
+    y1, s1 = conv_bn_fwd(cfg, x, blk.conv1, blk.bn1, True)
+    y2, s2 = conv_bn_fwd(cfg, y1, blk.conv2, blk.bn2, True)
+    sd = None
+    if ds is not None:
+        idn, sd = conv_bn_fwd(cfg, x, ds[0], ds[1], False)
+    else:
+        idn = x
+    out, s3 = conv_bn_fwd(cfg, y2, blk.conv3, blk.bn3, True, residual=idn)
+    return out, (s1, s2, s3, sd)
+
+
+def bottleneck_bwd(cfg, state, dout, blk):
+    """Returns (dx, [grads in blk.param_list() order])."""
+    s1, s2, s3, sd = state
+    dy2, dres, dw3, dg3, db3 = conv_bn_bwd(cfg, s3, dout, blk.conv3, blk.bn3, want_dres=True)
+    dy1, _, dw2, dg2, db2 = conv_bn_bwd(cfg, s2, dy2, blk.conv2, blk.bn2)
+    grads = [None] * 9
+    if sd is not None:
+        ds = blk.downsample
+        dxd, _, dwd, dgd, dbd = conv_bn_bwd(cfg, sd, dres, ds[0], ds[1])
+        dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_accum=dxd)
+        extra = [dwd, dgd, dbd]
+    else:
+        dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_accum=dres)
+        extra = []
+    grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3] + extra
+    return dx, grads
+
+
+# ------------------------------------------------------------------- head ----
+def head_fwd(cfg, x, head, train):
+    """DeepLabHead on NHWC features -> low-res logits [N,h,w,CPAD] fp32."""
+    aspp = head[0]
+    N, h, w, cin = x.shape
+    nb = len(aspp.convs)                      # 1x1 + atrous convs + pooling
+    mid = aspp.project[0].weight.shape[0]
+    cat = torch.empty((N, h, w, nb * mid), dtype=x.dtype, device=x.device)
+    states = []
+    for i in range(nb - 1):
+        seq = aspp.convs[i]
+        sl = cat[..., i * mid:(i + 1) * mid]
+        if train:
+            _, st = conv_bn_fwd(cfg, x, seq[0], seq[1], True, out=sl)
+            states.append(st)
+        else:
+            conv_bn_eval(cfg, x, seq[0], seq[1], True, out=sl)
+    # image pooling branch: GAP -> 1x1 conv -> BN -> ReLU -> broadcast
+    pool = aspp.convs[nb - 1]
+    g = K.sum_hw(x, 1.0 / (h * w)).view(N, 1, 1, cin)
+    if train:
+        pv, stp = conv_bn_fwd(cfg, g, pool[1], pool[2], True)
+        states.append(stp)
+    else:
+        pv = conv_bn_eval(cfg, g, pool[1], pool[2], True)
+    K.broadcast_hw(pv.view(N, mid), cat[..., (nb - 1) * mid:])
+    proj = aspp.project
+    seed = None
+    if train:
+        pr, stj = conv_bn_fwd(cfg, cat, proj[0], proj[1], True)
+        pdrop = proj[3].p
+        if pdrop > 0:
+            seed = cfg.next_seed()
+            pr_d = K.dropout(pr, pdrop, seed)
+        else:
+            pr_d = pr
+        q, stq = conv_bn_fwd(cfg, pr_d, head[1], head[2], True)
+    else:
+        pr_d = conv_bn_eval(cfg, cat, proj[0], proj[1], True)
+        q = conv_bn_eval(cfg, pr_d, head[1], head[2], True)
+        stj = stq = None
+    # classifier 1x1 (+bias) always in fp32, Cout padded to CPAD
+    cls = head[4]
+    q32 = q if q.dtype == torch.float32 else K.cast(q, torch.float32)
+    wf, _ = packed(cls, torch.float32, CPAD)
+    bias = cls.__dict__.get("_eeseg_bias_pad")
+    bkey = (cls.bias._version, _WEIGHTS_EPOCH[0], cls.bias.data_ptr())
+    if bias is None or bias[0] != bkey:
+        bp = torch.zeros(CPAD, dtype=torch.float32, device=x.device)
+        bp[:cls.bias.numel()] = cls.bias.detach()
+        bias = (bkey, bp)
+        cls.__dict__["_eeseg_bias_pad"] = bias
+    logits, _ = K.conv_fwd(q32, wf, shift=bias[1])
+    state = (x, cat, states, stj, seed, stq, q32) if train else None
+    return logits, state
+
+
+def head_bwd(cfg, state, dlogits, head):
+    """Returns (dx, grads in head.param_list() order)."""
+    x, cat, states, stj, seed, stq, q32 = state
+    aspp = head[0]
+    nb = len(aspp.convs)
+    mid = aspp.project[0].weight.shape[0]
+    N, h, w, cin = x.shape
+    cls = head[4]
+    ncls = cls.weight.shape[0]
+    # classifier
+    dbias = K.colsum(dlogits)[:ncls]
+    dwc = K.conv_wgrad(q32, dlogits, 1, 1)[:ncls].permute(0, 3, 1, 2)
+    _, wb = packed(cls, torch.float32, CPAD)
+    dq = K.conv_dgrad(dlogits, wb, (h, w))
+    if cfg.compute_dtype != torch.float32:
+        dq = K.cast(dq, cfg.compute_dtype)
+    # 3x3 conv + BN + ReLU
+    dpr_d, _, dw3, dg3, db3 = conv_bn_bwd(cfg, stq, dq, head[1], head[2])
+    proj = aspp.project
+    dpr = K.dropout(dpr_d, proj[3].p, seed) if seed is not None else dpr_d
+    dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
+    grads_convs = []
+    dx = None
+    for i in range(nb - 1):
+        seq = aspp.convs[i]
+        sl = dcat[..., i * mid:(i + 1) * mid]
+        dx, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], dx_accum=dx)
+        grads_convs += [dwi, dgi, dbi]
+    pool = aspp.convs[nb - 1]
+    dpv = K.sum_hw(dcat[..., (nb - 1) * mid:]).view(N, 1, 1, mid)
+    dg_, _, dwp, dgp, dbp = conv_bn_bwd(cfg, states[nb - 1], dpv, pool[1], pool[2])
+    K.broadcast_hw(dg_.view(N, cin), dx, scale=1.0 / (h * w), accumulate=True)
+    grads_convs += [dwp, dgp, dbp]
+    grads = grads_convs + [dwj, dgj, dbj, dw3, dg3, db3, dwc, dbias]
+    return dx, grads

@@ -396,11 +396,13 @@ def upsample_ce_fwd(lr, C_, target, H, W, ignore_index, accum):
                                       _stream()), "eeseg_upsample_ce_fwd")
 
 
-def upsample_ce_bwd(lr, C_, target, H, W, ignore_index, accum, gscale, dlr):
+def upsample_ce_bwd(lr, C_, target, H, W, ignore_index, accum, gscale, dlr, gscale_dev=None):
     N, h, w, ldc = _lr_dims(lr)
     assert dlr.shape == lr.shape and dlr.is_contiguous() and dlr.dtype == torch.float32
+    if gscale_dev is not None:
+        assert gscale_dev.dtype == torch.float32 and gscale_dev.numel() == 1 and gscale_dev.is_cuda
     check(lib().eeseg_upsample_ce_bwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, int(ignore_index), _p(accum),
-                                      float(gscale), _p(dlr), _stream()), "eeseg_upsample_ce_bwd")
+                                      float(gscale), _p(gscale_dev), _p(dlr), _stream()), "eeseg_upsample_ce_bwd")
 
 
 def argmax_confusion(lr, C_, target, H, W, counts=None, want_pred=False):

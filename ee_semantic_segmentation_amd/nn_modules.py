@@ -1,0 +1,281 @@
+"""nn.Module surface of the torchvision pieces the reference composes
+(SURVEY.md Appendix A), running on libeeseg.  Parameter / buffer names and shapes
+match torchvision exactly, so reference checkpoints load key-for-key:
+``conv1.weight``, ``bn1.{weight,bias,running_mean,running_var,num_batches_tracked}``,
+``downsample.{0,1}.*``, ``convs.{i}.{0,1}.*``, ``project.{0,1}.*`` ...
+
+Activations between these modules are NHWC tensors in the network's compute
+dtype; the stem takes the NCHW fp32 image, a head returns low-resolution fp32
+logits [N,h,w,32] (classes padded to one 128-byte row).
+"""
+import torch
+from torch import nn
+
+from . import engine as E
+
+
+# ---------------------------------------------------------------- holders ----
+class Conv2d(nn.Module):
+    """Parameter holder with torch.nn.Conv2d's attributes; weight is stored
+    channels_last (= KRSC, the kernels' layout) so weight gradients need no copy."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride = (k, k), (stride, stride)
+        self.padding, self.dilation = (padding, padding), (dilation, dilation)
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):   # torch.nn.Conv2d default init (heads keep it: SURVEY F7)
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / fan_in ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}")
+
+    def forward(self, x):
+        raise RuntimeError("Conv2d is fused by its parent block (stem / Bottleneck / DeepLabHead)")
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
+
+    def forward(self, x):
+        raise RuntimeError("BatchNorm2d is fused by its parent block")
+
+
+class ReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        raise RuntimeError("ReLU is fused by its parent block")
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, kernel_size=3, stride=2, padding=1):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        raise RuntimeError("MaxPool2d is fused into the stem")
+
+
+class AdaptiveAvgPool2d(nn.Module):
+    def __init__(self, output_size=1):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        raise RuntimeError("AdaptiveAvgPool2d is fused into the ASPP head")
+
+
+class Dropout(nn.Module):
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        raise RuntimeError("Dropout is fused into the ASPP head")
+
+
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ----------------------------------------------------------------- stem ------
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, w, g, b, conv, bn, cfg):
+        out, st = E.stem_fwd(cfg, img, conv, bn, True)
+        ctx.st, ctx.mods, ctx.cfg = st, (conv, bn), cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        conv, bn = ctx.mods
+        dw, dg, db = E.stem_bwd(ctx.cfg, ctx.st, dout.contiguous(), conv, bn)
+        ctx.st = None
+        return None, dw, dg, db, None, None, None
+
+
+def run_stem(cfg, img, conv, bn, train):
+    if train and _needs_grad(conv.weight, bn.weight, bn.bias):
+        return _StemFn.apply(img, conv.weight, bn.weight, bn.bias, conv, bn, cfg)
+    with torch.no_grad():
+        return E.stem_fwd(cfg, img, conv, bn, train)[0]
+
+
+# ------------------------------------------------------------ bottleneck -----
+class _BottleneckFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, blk, cfg, *params):
+        out, st = E.bottleneck_fwd(cfg, x, blk, True)
+        ctx.st, ctx.blk, ctx.cfg = st, blk, cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, grads = E.bottleneck_bwd(ctx.cfg, ctx.st, dout.contiguous(), ctx.blk)
+        ctx.st = None
+        return (dx, None, None, *grads)
+
+
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck (Appendix A.1)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, cfg=None):
+        super().__init__()
+        w = planes
+        self.conv1 = Conv2d(inplanes, w, 1)
+        self.bn1 = BatchNorm2d(w)
+        self.conv2 = Conv2d(w, w, 3, stride=stride, padding=dilation, dilation=dilation)
+        self.bn2 = BatchNorm2d(w)
+        self.conv3 = Conv2d(w, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.__dict__["cfg"] = cfg
+
+    def param_list(self):
+        ps = [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
+              self.conv3.weight, self.bn3.weight, self.bn3.bias]
+        if self.downsample is not None:
+            ps += [self.downsample[0].weight, self.downsample[1].weight, self.downsample[1].bias]
+        return ps
+
+    def forward(self, x):
+        cfg = self.__dict__["cfg"]
+        ps = self.param_list()
+        if self.training and _needs_grad(x, *ps):
+            return _BottleneckFn.apply(x, self, cfg, *ps)
+        if self.training:
+            with torch.no_grad():
+                return E.bottleneck_fwd(cfg, x, self, True)[0]
+        if _needs_grad(x, *ps):
+            raise RuntimeError("backward through eval-mode (frozen BatchNorm) blocks is not implemented; "
+                               "call .train() or wrap in torch.no_grad()")
+        with torch.no_grad():
+            return E.bottleneck_fwd(cfg, x, self, False)[0]
+
+
+# ------------------------------------------------------------------ head -----
+class ASPPConv(nn.Sequential):
+    def __init__(self, cin, cout, dilation):
+        super().__init__(Conv2d(cin, cout, 3, padding=dilation, dilation=dilation), BatchNorm2d(cout), ReLU())
+
+
+class ASPPPooling(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(AdaptiveAvgPool2d(1), Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU())
+
+
+class ASPP(nn.Module):
+    def __init__(self, cin, atrous_rates=(12, 24, 36), cout=256):
+        super().__init__()
+        mods = [nn.Sequential(Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU())]
+        for r in atrous_rates:
+            mods.append(ASPPConv(cin, cout, r))
+        mods.append(ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(Conv2d(len(mods) * cout, cout, 1), BatchNorm2d(cout), ReLU(), Dropout(0.5))
+
+    def forward(self, x):
+        raise RuntimeError("ASPP is fused by DeepLabHead")
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, head, cfg, *params):
+        logits, st = E.head_fwd(cfg, x, head, True)
+        ctx.st, ctx.head, ctx.cfg = st, head, cfg
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dx, grads = E.head_bwd(ctx.cfg, ctx.st, dlogits.contiguous(), ctx.head)
+        ctx.st = None
+        return (dx, None, None, *grads)
+
+
+class DeepLabHead(nn.Sequential):
+    """torchvision DeepLabHead (Appendix A.2): ASPP -> 3x3 -> BN -> ReLU -> 1x1(+bias).
+    Returns low-resolution logits [N,h,w,32] fp32 (first `num_classes` channels valid)."""
+
+    def __init__(self, cin, num_classes, atrous_rates=(12, 24, 36), mid=256, cfg=None):
+        if num_classes > E.CPAD:
+            raise ValueError(f"at most {E.CPAD} classes are supported by the fused loss kernels")
+        super().__init__(ASPP(cin, atrous_rates, mid), Conv2d(mid, mid, 3, padding=1), BatchNorm2d(mid), ReLU(),
+                         Conv2d(mid, num_classes, 1, bias=True))
+        self.__dict__["cfg"] = cfg
+        self.num_classes = num_classes
+
+    def param_list(self):
+        ps = []
+        aspp = self[0]
+        for i, seq in enumerate(aspp.convs):
+            conv, bn = (seq[1], seq[2]) if isinstance(seq, ASPPPooling) else (seq[0], seq[1])
+            ps += [conv.weight, bn.weight, bn.bias]
+        ps += [aspp.project[0].weight, aspp.project[1].weight, aspp.project[1].bias,
+               self[1].weight, self[2].weight, self[2].bias, self[4].weight, self[4].bias]
+        return ps
+
+    def forward(self, x):
+        cfg = self.__dict__["cfg"]
+        ps = self.param_list()
+        if self.training and _needs_grad(x, *ps):
+            return _HeadFn.apply(x, self, cfg, *ps)
+        if self.training:
+            with torch.no_grad():
+                return E.head_fwd(cfg, x, self, True)[0]
+        if _needs_grad(x, *ps):
+            raise RuntimeError("backward through an eval-mode head is not implemented; call .train()")
+        with torch.no_grad():
+            return E.head_fwd(cfg, x, self, False)[0]
+
+
+class Section(nn.Sequential):
+    """One backbone section (from_deepv3_new.py:84,90).  Section 0 starts with the
+    stem modules [conv1, bn1, relu, maxpool] which run as one fused stem."""
+
+    def __init__(self, *mods, cfg=None):
+        super().__init__(*mods)
+        self.__dict__["cfg"] = cfg
+
+    def forward(self, x):
+        cfg = self.__dict__["cfg"]
+        mods = list(self)
+        i = 0
+        if mods and isinstance(mods[0], Conv2d):
+            x = run_stem(cfg, x, mods[0], mods[1], self.training and mods[1].training)
+            i = 4
+        for m in mods[i:]:
+            x = m(x)
+        return x

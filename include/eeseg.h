@@ -170,11 +170,12 @@ int eeseg_upsample_bilinear_nchw_bwd(const float* dout, float* dlogits_lr, int l
  * [1] += #valid.  Labels outside [0,C) are treated as ignored. */
 int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
                           int H, int W, int64_t ignore_index, double* accum /*[2]*/, void* stream);
-/* dlogits_lr += gscale/accum[1] * d(sum CE)/d(logits_lr)  (reads the valid count
- * from device memory: no host sync).  The caller zeroes dlogits_lr. */
+/* dlogits_lr += gscale*gscale_dev[0]/accum[1] * d(sum CE)/d(logits_lr).  The valid
+ * count and the optional upstream gradient scalar (gscale_dev, may be NULL) are
+ * read from device memory: no host sync.  The caller zeroes dlogits_lr. */
 int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
                           int H, int W, int64_t ignore_index, const double* accum, float gscale,
-                          float* dlogits_lr, void* stream);
+                          const float* gscale_dev, float* dlogits_lr, void* stream);
 /* Fused upsample + argmax + TP/FP/FN (seg_metrics.py:13-28 + compute_mIoU.py:16-27):
  * counts[3][C] int32 (+= per call, exact); void pixels (label outside [0,C))
  * count as FP of the predicted class (B-9).  pred (optional) receives the argmax
