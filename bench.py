@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one data-parallel training step (forward +
+backward + SGD step) of the early-exit DeepLabV3 on synthetic 513x513 batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload at N=1 = BASELINE.json configs[1]: DeepLabV3-ResNet50, 2 exits, 513x513,
+B=16, 21 classes, bf16 MFMA compute (fp32 master weights / statistics / loss).
+N>1 keeps 16 images per GPU (weak scaling); gradients are all-reduced over RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
+(live HIP-event timing of the dominant conv kernel family vs the dense bf16 MFMA
+peak) and, at N=1, `cpu_baseline` (the oracle = torch CPU fp32 restatement of the
+reference path, timed on a bounded sample on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(B, C, H, W, seed, device):
+    """randn image, piecewise-constant labels (32x32 blocks), ~5% void = C."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(B, 3, H, W, generator=g)
+    blocks = torch.randint(0, C, (B, 1, (H + 31) // 32, (W + 31) // 32), generator=g).float()
+    y = torch.nn.functional.interpolate(blocks, size=(H, W), mode="nearest").long()
+    y[torch.rand(B, 1, H, W, generator=g) < 0.05] = C
+    return X.to(device), y.to(device)
+
+
+def cpu_baseline(arch, n_branches, C, img, B, seed):
+    """One timed fwd+bwd+SGD step of the ORACLE (torch CPU fp32, reference-shaped loss
+    path: unfused upsample -> stacked tensor -> per-exit CE) on this host's cores."""
+    from oracle.deeplab_ref import branchyDeepv3 as Ref
+    from oracle import losses_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    ref = Ref(f"deeplabv3_{arch}", n_branches, img, count_branches=False, num_classes=C).train()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    X, y = synth_batch(B, C, img, img, seed, "cpu")
+
+    def step(x, t):
+        out = ref(x)
+        l = losses_ref.br_xentropy(out, t, ignore_index=C, b_reduction="sum", n_exits=n_branches + 1)
+        opt.zero_grad()
+        l.mean().backward()
+        opt.step()
+
+    xs, ts = synth_batch(2, C, 65, 65, seed, "cpu")
+    step(xs, ts)                                   # page in kernels / allocator
+    t0 = time.perf_counter()
+    step(X, y)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 timed fwd+bwd+SGD step of the torch-CPU fp32 oracle, {arch} {n_branches + 1} exits, "
+                      f"{img}x{img}, B={B} ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--branches", type=int, default=1)
+    ap.add_argument("--img", type=int, default=513)
+    ap.add_argument("--batch-per-gpu", type=int, default=16)
+    ap.add_argument("--classes", type=int, default=21)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+
+    from ee_semantic_segmentation_amd import kernels as K
+    from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    from ee_semantic_segmentation_amd.optim import SGD
+    from ee_semantic_segmentation_amd.parallel import GradReducer, broadcast_parameters
+
+    C, img, B = args.classes, args.img, args.batch_per_gpu
+    torch.manual_seed(0)
+    net = branchyDeepv3(None, f"deeplabv3_{args.arch}", args.branches, img, count_branches=False, num_classes=C,
+                        compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
+                        fused_outputs=True).to(dev)
+    net.cfg.sync_bn = args.sync_bn and world > 1
+    broadcast_parameters(net)
+    E = net.n_branches + 1
+    crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)
+    lr = 0.01                                                  # param groups as deepv3_funcs.py:74-99
+    opt = SGD([{"params": net.base_model.parameters(), "lr": lr},
+               {"params": net.branches.parameters(), "lr": lr},
+               {"params": net.classifier.parameters(), "lr": lr * 1.1}], lr=lr, momentum=0.9, weight_decay=5e-4)
+    reducer = GradReducer(net)
+    X, y = synth_batch(B, C, img, img, 1234 + rank, dev)
+    net.train()
+
+    def step():
+        out = net(X)
+        l = crit(out, y)
+        opt.zero_grad(set_to_none=True)
+        l.mean().backward()
+        reducer.finish()
+        opt.step()
+        return l
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    if not args.no_kernel_events:
+        K.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, K.PROFILE = K.PROFILE, None
+    loss_val = float(last.item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        flop_img = 3 * 2.0 * net.macs(img)                    # fwd + bwd = 3 x fwd, FLOP = 2 MAC
+        roof = None
+        if prof:
+            fam = {}
+            for name, flops, e0, e1 in prof:
+                f = fam.setdefault(name, [0.0, 0.0, 0])
+                f[0] += flops
+                f[1] += e0.elapsed_time(e1) * 1e-3
+                f[2] += 1
+            name, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
+            roof = {"kernel": name, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS
+                    if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": fl / sec / 1e12 /
+                    (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
+                    "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+                    "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / args.steps * 1e3,
+                                     "launches_per_step": v[2] / args.steps} for k, v in fam.items()},
+                    "whole_step_tflops": value / world * flop_img / 1e12}
+        line = {"metric": "images/sec at 513x513 fwd+bwd+SGD step (early-exit DeepLabV3 training)",
+                "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
+                                       f"per-exit CE (sum), SGD momentum 0.9 wd 5e-4",
+                           "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
+                           "flop_per_image": flop_img, "loss_last_step": loss_val},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.arch, args.branches, C, img, 2, 1234)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,26 @@ def rows_ld(t):
 
 _ws = {}
 
+# When set to a list, every conv launch appends (kernel family, algorithmic FLOPs,
+# start event, end event) - bench.py uses it for the live roofline measurement.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev, family, flops):
+    if ev is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    PROFILE.append((family, flops, ev, end))
+
 
 def workspace(nbytes, device):
     key = str(device)
@@ -93,7 +113,12 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, Hin, Win, Cin, Hout, Wout, Cout, R, S
     a.smul, a.off_h, a.off_w, a.tstep_h, a.tstep_w, a.sdiv = smul, off, off, tstep, tstep, sdiv
     a.ldy, a.ldres, a.relu, a.dtype = ldy, ldres, int(relu), _dt(x)
+    ev = _prof_begin()
     check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
+    if ev is not None:
+        px = N * (Hin * Win if sdiv > 1 else Hout * Wout)      # algorithmic MACs (padding taps included)
+        fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
+        _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S)
 
 
 def conv_fwd(x, w, stride=1, pad=0, dil=1, *, want_stats=False, scale=None, shift=None, residual=None,
@@ -156,7 +181,11 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
     a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cin, Ho, Wo, Cout, R, S
     a.stride, a.pad, a.dil, a.dtype, a.accumulate = stride, pad, dil, _dt(x), int(accumulate)
+    ev = _prof_begin()
     check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
+    if ev is not None:
+        _prof_end(ev, f"conv_wgrad_kernel<{'bf16' if a.dtype == BF16 else 'f32'}>",
+                  2.0 * N * Ho * Wo * Cout * Cin * R * S)
     return out
 
 
