@@ -44,7 +44,8 @@ def cpu_baseline(arch, n_branches, C, img, B, seed):
     path: unfused upsample -> stacked tensor -> per-exit CE) on this host's cores."""
     from oracle.deeplab_ref import branchyDeepv3 as Ref
     from oracle import losses_ref
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))                 # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = Ref(f"deeplabv3_{arch}", n_branches, img, count_branches=False, num_classes=C).train()
@@ -66,6 +67,10 @@ def cpu_baseline(arch, n_branches, C, img, B, seed):
     return {"value": B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"1 timed fwd+bwd+SGD step of the torch-CPU fp32 oracle, {arch} {n_branches + 1} exits, "
                       f"{img}x{img}, B={B} ({dt:.1f} s)"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -128,8 +133,12 @@ def main():
         opt.step()
         return l
 
-    for _ in range(args.warmup):
-        step()
+    log(f"model ready: {args.arch} E={E} {img}x{img} B={B}/GPU {args.dtype}; warmup {args.warmup}")
+    for i in range(args.warmup):
+        l = step()
+        if rank == 0:
+            torch.cuda.synchronize()
+            log(f"warmup {i} done, loss {float(l.item()):.4f}")
 
     def fence():
         torch.cuda.synchronize()
@@ -145,6 +154,7 @@ def main():
         last = step()
     fence()
     dt = time.perf_counter() - t0
+    log(f"timed {args.steps} steps in {dt:.3f} s")
     prof, K.PROFILE = K.PROFILE, None
     loss_val = float(last.item())
     if world > 1:
@@ -182,7 +192,9 @@ def main():
                            "flop_per_image": flop_img, "loss_last_step": loss_val},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle, torch CPU fp32) ...")
             line["cpu_baseline"] = cpu_baseline(args.arch, args.branches, C, img, 2, 1234)
+            log("cpu baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -6,6 +6,8 @@ raises - there is no CPU/PyTorch fallback anywhere in the package.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (loads torch's bundled libamdhip64 FIRST so libeeseg binds to the same HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeeseg.so")
 

@@ -27,7 +27,7 @@ def _digest():
     inc = os.path.join(HERE, "..", "include", "eeseg.h")
     for p in sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [inc]:
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
