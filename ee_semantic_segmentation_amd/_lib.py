@@ -46,7 +46,7 @@ SIGNATURES = {
     "eeseg_pack_matrix": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "eeseg_im2col_nchw": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "eeseg_colreduce_workspace": (_i64, [_i64, _i]),
-    "eeseg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp]),
+    "eeseg_bn_reduce_partials": (_i, [_vp, _i, _i, _vp, _vp, _i64, _vp]),
     "eeseg_bn_finalize": (_i, [_vp, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "eeseg_bn_eval_scale_shift": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp]),
     "eeseg_bn_apply": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _i, _vp]),

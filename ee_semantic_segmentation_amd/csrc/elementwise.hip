@@ -110,13 +110,17 @@ struct StatsOp {   // sum x, sum x^2
     template <typename T> struct Args { const T* x; int ldx; };
 };
 
+// block = 256 threads arranged as TX chunk-columns x (256/TX) row lanes, TX = min(32, C/EPC)
+// (power of two), so narrow tensors (C = 64) still use every thread.
 template <typename T, int K, typename F>
-__device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, long long row_end, int C,
+__device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, long long row_end, int C, int TX,
                                                float* out /* [K][C] for this (rowblock,batch) */) {
     constexpr int EPC = 16 / (int)sizeof(T);
-    __shared__ float sred[8][32][K * EPC + 1];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int chunk = blockIdx.x * 32 + tx;
+    constexpr int KE = K * EPC;
+    __shared__ float sred[256][KE + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid % TX, ty = tid / TX, TY = 256 / TX;
+    const int chunk = blockIdx.x * TX + tx;
     const int c0 = chunk * EPC;
     float acc[K][EPC];
 #pragma unroll
@@ -124,29 +128,26 @@ __device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, lo
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[k][e] = 0.f;
     if (c0 < C) {
-        for (long long r = row_begin + ty; r < row_end; r += 8) elem(r, c0, acc);
+        for (long long r = row_begin + ty; r < row_end; r += TY) elem(r, c0, acc);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) sred[ty][tx][k * EPC + e] = acc[k][e];
+        for (int e = 0; e < EPC; ++e) sred[tid][k * EPC + e] = acc[k][e];
     __syncthreads();
-    // 256 threads sum the 8 row lanes for 32*K*EPC values
-    const int t = ty * 32 + tx;
-    for (int v = t; v < 32 * K * EPC; v += 256) {
-        const int col = v / (K * EPC), ke = v - col * (K * EPC);
+    for (int v = tid; v < TX * KE; v += 256) {
+        const int col = v / KE, ke = v - col * KE;
         float s = 0.f;
-#pragma unroll
-        for (int y = 0; y < 8; ++y) s += sred[y][col][ke];
+        for (int yy = 0; yy < TY; ++yy) s += sred[yy * TX + col][ke];
         const int k = ke / EPC, e = ke - k * EPC;
-        const int cg = (blockIdx.x * 32 + col) * EPC + e;
+        const int cg = (blockIdx.x * TX + col) * EPC + e;
         if (cg < C) out[(long long)k * C + cg] = s;
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void stats_stage1(const T* x, int ldx, long long rows, long long rows_per_block,
-                                                    int C, float* partials) {
+                                                    int C, int TX, float* partials) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long rb = (long long)blockIdx.y * rows_per_block;
     const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
@@ -160,12 +161,12 @@ __global__ __launch_bounds__(256) void stats_stage1(const T* x, int ldx, long lo
                 acc[1][e] += f * f;
             }
         },
-        rb, re, C, partials + (long long)blockIdx.y * 2 * C);
+        rb, re, C, TX, partials + (long long)blockIdx.y * 2 * C);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_stage1(const T* x, int ldx, long long rows, long long rows_per_block,
-                                                     int C, float* partials) {
+                                                     int C, int TX, float* partials) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long rb = (long long)blockIdx.y * rows_per_block;
     const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
@@ -175,17 +176,17 @@ __global__ __launch_bounds__(256) void colsum_stage1(const T* x, int ldx, long l
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[0][e] += to_f32(v.e[e]);
         },
-        rb, re, C, partials + (long long)blockIdx.y * C);
+        rb, re, C, TX, partials + (long long)blockIdx.y * C);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, const T* y, int ldy, const T* x, int ldx,
                                                      const float* mean_invstd, long long rows,
-                                                     long long rows_per_block, int C, int relu, float* partials) {
+                                                     long long rows_per_block, int C, int relu, int TX, float* partials) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long rb = (long long)blockIdx.y * rows_per_block;
     const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
-    const int c0t = (blockIdx.x * 32 + threadIdx.x) * EPC;
+    const int c0t = (blockIdx.x * TX + (threadIdx.x % TX)) * EPC;
     float mu[EPC], is[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -208,22 +209,39 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, cons
                 acc[1][e] += gf * xh;
             }
         },
-        rb, re, C, partials + (long long)blockIdx.y * 2 * C);
+        rb, re, C, TX, partials + (long long)blockIdx.y * 2 * C);
 }
 
-// stage 2: partials[tiles][KC] -> out[KC]   (KC = K*C flattened), double accumulation
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int tiles, int KC,
-                                                              float* out) {
-    __shared__ double sred[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;
+// partials[tiles][KC] -> out[seg][KC]: block = 64 columns x 16 row lanes, grid.y = segments
+// of the tile range (a second call folds the segments).  Fixed order -> deterministic.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int tiles, int KC,
+                                                               int tiles_per_seg, float* out) {
+    __shared__ double sred[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int t0 = blockIdx.y * tiles_per_seg;
+    const int t1 = min(tiles, t0 + tiles_per_seg);
     double s = 0.0;
-    if (col < KC)
-        for (int t = g; t < tiles; t += 4) s += (double)partials[(long long)t * KC + col];
-    sred[g][threadIdx.x & 63] = s;
+    if (col < KC) {
+        int t = t0 + g;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (; t + 48 < t1; t += 64) {      // 4 independent loads in flight
+            a0 += partials[(long long)t * KC + col];
+            a1 += partials[(long long)(t + 16) * KC + col];
+            a2 += partials[(long long)(t + 32) * KC + col];
+            a3 += partials[(long long)(t + 48) * KC + col];
+        }
+        for (; t < t1; t += 16) a0 += partials[(long long)t * KC + col];
+        s = (double)a0 + (double)a1 + (double)a2 + (double)a3;
+    }
+    sred[g][lane] = s;
     __syncthreads();
-    if (g == 0 && col < KC) out[col] = (float)(sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] +
-                                               sred[3][threadIdx.x]);
+    if (g == 0 && col < KC) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sred[i][lane];
+        out[(long long)blockIdx.y * KC + col] = (float)t;
+    }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, const float* gamma,
@@ -262,25 +280,30 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 // =========================================================================
 // elementwise passes over [rows][C] with row strides
 // =========================================================================
+// Column-fixed mapping: the host picks gridDim so that (gridDim.x*256) % (C/EPC) == 0, so a
+// thread owns ONE 16-byte channel chunk for its whole grid-stride loop and keeps the
+// per-channel coefficients in registers (no per-element div/mod or coefficient loads).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
                                                        int C, int relu) {
     constexpr int EPC = 16 / (int)sizeof(TI);
     const int cpr = C / EPC;
-    const long long total = rows * cpr;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cpr);
-        const long long r = i / cpr;
-        const int c0 = ch * EPC;
+    const long long gid = blockIdx.x * 256ll + threadIdx.x;
+    const long long T = gridDim.x * 256ll;
+    const int c0 = (int)(gid % cpr) * EPC;
+    const long long rstep = T / cpr;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
+    for (long long r = gid / cpr; r < rows; r += rstep) {
         Vec<TI> v = ld16(x + r * ldx + c0);
         Vec<TI> rv;
         if (res) rv = ld16(res + r * ldres + c0);
         float o[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            float f = to_f32(v.e[e]) * ss[c0 + e] + ss[C + c0 + e];
+            float f = to_f32(v.e[e]) * sc[e] + sh[e];
             if (res) f += to_f32(rv.e[e]);
             if (relu) f = fmaxf(f, 0.f);
             o[e] = f;
@@ -311,12 +334,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
                                                            int relu) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int cpr = C / EPC;
-    const long long total = rows * cpr;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cpr);
-        const long long r = i / cpr;
-        const int c0 = ch * EPC;
+    const long long gid = blockIdx.x * 256ll + threadIdx.x;
+    const long long T_ = gridDim.x * 256ll;
+    const int c0 = (int)(gid % cpr) * EPC;
+    const long long rstep = T_ / cpr;
+    // dx = ka*g + kb*(x - mean) + kc   (MODE 0: ka = gamma*invstd, kb = -ka*invstd^2*s1/n, kc = -ka*s0/n)
+    float ka[EPC], kb[EPC], kc[EPC], km[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = c0 + e;
+        if (MODE == 0) {
+            const float mu = mean_invstd[c], is = mean_invstd[C + c];
+            const float ga = gamma ? gamma[c] : 1.f;
+            ka[e] = ga * is;
+            kb[e] = -ka[e] * is * is * sums[C + c] * inv_count;
+            kc[e] = -ka[e] * sums[c] * inv_count;
+            km[e] = mu;
+        } else {
+            ka[e] = gamma[c]; kb[e] = 0.f; kc[e] = 0.f; km[e] = 0.f;      // gamma := scale
+        }
+    }
+    for (long long r = gid / cpr; r < rows; r += rstep) {
         Vec<T> g = ld16(dy + r * lddy + c0);
         Vec<T> yv, xv;
         if (relu) yv = ld16(y + r * ldy + c0);
@@ -327,16 +365,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
             float gf = to_f32(g.e[e]);
             if (relu && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
             og.e[e] = from_f32<T>(gf);
-            float d;
-            if (MODE == 0) {
-                const int c = c0 + e;
-                const float mu = mean_invstd[c], is = mean_invstd[C + c];
-                const float xh = (to_f32(xv.e[e]) - mu) * is;
-                const float ga = gamma ? gamma[c] : 1.f;
-                d = ga * is * (gf - sums[c] * inv_count - xh * sums[C + c] * inv_count);
-            } else {
-                d = gf * gamma[c0 + e];   // gamma := scale
-            }
+            float d = ka[e] * gf;
+            if (MODE == 0) d += kb[e] * (to_f32(xv.e[e]) - km[e]) + kc[e];
             od.e[e] = from_f32<T>(d);
         }
         st16(dx + r * lddx + c0, od);
@@ -533,6 +563,19 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* y, const T* x, long
     }
 }
 
+// grid for the column-fixed kernels: total threads must be a multiple of chunks-per-row
+inline int colfixed_grid(long long rows, int cpr) {
+    long long items = rows * cpr;
+    long long b = (items + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    int a = cpr, c = 256;                       // m = cpr / gcd(cpr, 256)
+    while (c) { int t = a % c; a = c; c = t; }
+    const int m = cpr / a;
+    b = (b + m - 1) / m * m;
+    return (int)b;
+}
+
 // ---- host-side helpers ----------------------------------------------------
 struct RowSplit { int blocks; long long rows_per_block; };
 inline RowSplit row_split(long long rows) {
@@ -635,13 +678,37 @@ extern "C" int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, i
 }
 
 extern "C" int64_t eeseg_colreduce_workspace(int64_t rows, int C) {
-    return (int64_t)row_split(rows).blocks * 2 * C * (int64_t)sizeof(float);
+    return ((int64_t)row_split(rows).blocks + 32) * 2 * C * (int64_t)sizeof(float);
 }
 
-extern "C" int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* stream) {
+static int launch_reduce_partials(const float* partials, int tiles, int KC, float* out, float* scratch,
+                                  hipStream_t st) {
+    const int colblocks = (KC + 63) / 64;
+    int segs = 1;
+    if (tiles >= 512 && scratch) {
+        segs = tiles / 128;
+        if (segs > 32) segs = 32;
+    }
+    if (segs > 1) {
+        const int tps = (tiles + segs - 1) / segs;
+        segs = (tiles + tps - 1) / tps;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, segs), dim3(1024), 0, st, partials, tiles, KC, tps,
+                           scratch);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, 1), dim3(1024), 0, st, (const float*)scratch, segs,
+                           KC, segs, out);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, 1), dim3(1024), 0, st, partials, tiles, KC, tiles,
+                           out);
+    }
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
     EESEG_CHECK(partials && sums && tiles > 0 && KC > 0, EESEG_ERR_ARG, "bn_reduce_partials: bad argument");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((KC + 63) / 64), dim3(256), 0, (hipStream_t)stream, partials, tiles,
-                       KC, sums);
+    float* scratch = (workspace && workspace_bytes >= (int64_t)32 * KC * (int64_t)sizeof(float)) ? (float*)workspace
+                                                                                                   : nullptr;
+    launch_reduce_partials(partials, tiles, KC, sums, scratch, (hipStream_t)stream);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -677,7 +744,7 @@ extern "C" int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, 
     EESEG_CHECK(((uintptr_t)y & 15) == 0 && ldy >= C && ldy % 4 == 0, EESEG_ERR_ARG, "bn_apply: bad y/ldy");
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(in_dtype);
-    const int g = ew_grid(rows * (C / epc));
+    const int g = colfixed_grid(rows, C / epc);
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
@@ -695,24 +762,29 @@ extern "C" int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, 
     return EESEG_OK;
 }
 
-// launches stage1 via `launch1(grid, partial_ptr)` then stage 2 when needed
+// launches stage1 via `launch1(grid, rows_per_block, TX, partial_ptr)` then stage 2 when needed
 template <typename L>
 static int two_stage(L&& launch1, int64_t rows, int C, int K, int epc, float* out, void* workspace,
                      int64_t workspace_bytes, hipStream_t st) {
     const RowSplit rs = row_split(rows);
-    const int colblocks = (C / epc + 31) / 32;
+    const int cpr = C / epc;
+    int TX = 32;
+    while (TX > cpr) TX >>= 1;
+    if (TX < 1) TX = 1;
+    const int colblocks = (cpr + TX - 1) / TX;
     float* partials = out;
+    float* scratch = nullptr;
     if (rs.blocks > 1) {
-        EESEG_CHECK(workspace && workspace_bytes >= (int64_t)rs.blocks * K * C * (int64_t)sizeof(float), EESEG_ERR_ARG,
-                    "column reduce: workspace too small (%lld bytes needed)",
-                    (long long)rs.blocks * K * C * (long long)sizeof(float));
+        const int64_t need = ((int64_t)rs.blocks + 32) * K * C * (int64_t)sizeof(float);
+        EESEG_CHECK(workspace && workspace_bytes >= need, EESEG_ERR_ARG,
+                    "column reduce: workspace too small (%lld bytes needed)", (long long)need);
         partials = (float*)workspace;
+        scratch = partials + (int64_t)rs.blocks * K * C;
     }
-    launch1(dim3(colblocks, rs.blocks), rs.rows_per_block, partials);
+    launch1(dim3(colblocks, rs.blocks), rs.rows_per_block, TX, partials);
     EESEG_LAUNCH_CHECK();
     if (rs.blocks > 1) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, partials, rs.blocks, K * C,
-                           out);
+        launch_reduce_partials(partials, rs.blocks, K * C, out, scratch, st);
         EESEG_LAUNCH_CHECK();
     }
     return EESEG_OK;
@@ -724,13 +796,12 @@ extern "C" int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, 
     CHECK_ROWS("channel_stats", x, ldx, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EESEG_BF16)
-        return two_stage([&](dim3 g, long long rpb, float* part) {
-            hipLaunchKernelGGL((stats_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (long long)rows, rpb,
-                               C, part);
+        return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+            hipLaunchKernelGGL((stats_stage1<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, (long long)rows, rpb,
+                               C, TX, part);
         }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
-    return two_stage([&](dim3 g, long long rpb, float* part) {
-        hipLaunchKernelGGL((stats_stage1<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (long long)rows, rpb, C,
-                           part);
+    return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+        hipLaunchKernelGGL((stats_stage1<float>), g, dim3(256), 0, st, (const float*)x, ldx, (long long)rows, rpb, C, TX, part);
     }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
 }
 
@@ -740,13 +811,12 @@ extern "C" int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* 
     CHECK_ROWS("colsum", x, ldx, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EESEG_BF16)
-        return two_stage([&](dim3 g, long long rpb, float* part) {
-            hipLaunchKernelGGL((colsum_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (long long)rows,
-                               rpb, C, part);
+        return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+            hipLaunchKernelGGL((colsum_stage1<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)x, ldx, (long long)rows,
+                               rpb, C, TX, part);
         }, rows, C, 1, 8, out, workspace, workspace_bytes, st);
-    return two_stage([&](dim3 g, long long rpb, float* part) {
-        hipLaunchKernelGGL((colsum_stage1<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (long long)rows, rpb, C,
-                           part);
+    return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+        hipLaunchKernelGGL((colsum_stage1<float>), g, dim3(256), 0, st, (const float*)x, ldx, (long long)rows, rpb, C, TX, part);
     }, rows, C, 1, 4, out, workspace, workspace_bytes, st);
 }
 
@@ -759,13 +829,13 @@ extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
     if (relu) CHECK_ROWS("bn_bwd_reduce y", y, ldy, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EESEG_BF16)
-        return two_stage([&](dim3 g, long long rpb, float* part) {
-            hipLaunchKernelGGL((bn_bwd_stage1<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)y,
-                               ldy, (const bf16_t*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, part);
+        return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+            hipLaunchKernelGGL((bn_bwd_stage1<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)y,
+                               ldy, (const bf16_t*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, TX, part);
         }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
-    return two_stage([&](dim3 g, long long rpb, float* part) {
-        hipLaunchKernelGGL((bn_bwd_stage1<float>), g, dim3(32, 8), 0, st, (const float*)dy, lddy, (const float*)y, ldy,
-                           (const float*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, part);
+    return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
+        hipLaunchKernelGGL((bn_bwd_stage1<float>), g, dim3(256), 0, st, (const float*)dy, lddy, (const float*)y, ldy,
+                           (const float*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, TX, part);
     }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
 }
 
@@ -782,7 +852,7 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     if (dres) CHECK_ROWS("bn_bwd_apply dres", dres, lddres, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
-    const int g = ew_grid(rows * (C / epc));
+    const int g = colfixed_grid(rows, C / epc);
     const float inv = (float)(1.0 / count);
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
@@ -806,7 +876,7 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
     if (dres) CHECK_ROWS("scale_act_bwd dres", dres, lddres, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
-    const int g = ew_grid(rows * (C / epc));
+    const int g = colfixed_grid(rows, C / epc);
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,

@@ -239,7 +239,9 @@ def reduce_partials(partials):
     tiles = partials.shape[0]
     kc = partials[0].numel()
     out = torch.empty(partials.shape[1:], dtype=torch.float32, device=partials.device)
-    check(lib().eeseg_bn_reduce_partials(_p(partials), tiles, kc, _p(out), _stream()), "eeseg_bn_reduce_partials")
+    ws = workspace(32 * kc * 4, partials.device)
+    check(lib().eeseg_bn_reduce_partials(_p(partials), tiles, kc, _p(out), _p(ws), ws.numel(), _stream()),
+          "eeseg_bn_reduce_partials")
     return out
 
 

@@ -99,8 +99,10 @@ int eeseg_im2col_nchw(const float* x, void* col, int N, int C, int H, int W, int
  * Column reductions over more than one row block need a workspace of
  * eeseg_colreduce_workspace(rows, C) bytes. */
 int64_t eeseg_colreduce_workspace(int64_t rows, int C);
-/* partials[tiles][KC] -> sums[KC] (fixed order, double accumulation) */
-int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* stream);
+/* partials[tiles][KC] -> sums[KC] (fixed order, double accumulation); an optional
+ * workspace of >= 32*KC floats enables the two-level reduction for many tiles */
+int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* sums, void* workspace,
+                             int64_t workspace_bytes, void* stream);
 int eeseg_bn_finalize(const float* sums /*[2][C]*/, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var,
                       float* mean_invstd, float* scale_shift, int C, void* stream);
