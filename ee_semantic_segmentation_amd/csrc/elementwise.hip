@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     const long long T_ = gridDim.x * 256ll;
     const int c0 = (int)(gid % cpr) * EPC;
     const long long rstep = T_ / cpr;
-    // dx = ka*g + kb*(x - mean) + kc   (MODE 0: ka = gamma*invstd, kb = -ka*invstd^2*s1/n, kc = -ka*s0/n)
+    // dx = ka*g + kb*(x - mean) + kc   (MODE 0: ka = gamma*invstd, kb = -ka*invstd*s1/n, kc = -ka*s0/n)
     float ka[EPC], kb[EPC], kc[EPC], km[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
             const float mu = mean_invstd[c], is = mean_invstd[C + c];
             const float ga = gamma ? gamma[c] : 1.f;
             ka[e] = ga * is;
-            kb[e] = -ka[e] * is * is * sums[C + c] * inv_count;
+            kb[e] = -ka[e] * is * sums[C + c] * inv_count;
             kc[e] = -ka[e] * sums[c] * inv_count;
             km[e] = mu;
         } else {
