@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no HIP-graph replay)")
+    ap.add_argument("--roofline-steps", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +107,7 @@ def main():
     from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
     from ee_semantic_segmentation_amd.optim import SGD
-    from ee_semantic_segmentation_amd.parallel import GradReducer, broadcast_parameters
+    from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, broadcast_parameters
 
     C, img, B = args.classes, args.img, args.batch_per_gpu
     torch.manual_seed(0)
@@ -120,21 +122,19 @@ def main():
     opt = SGD([{"params": net.base_model.parameters(), "lr": lr},
                {"params": net.branches.parameters(), "lr": lr},
                {"params": net.classifier.parameters(), "lr": lr * 1.1}], lr=lr, momentum=0.9, weight_decay=5e-4)
-    reducer = GradReducer(net)
+    net.enable_grad_arena()
+    reducer = ArenaReducer(net)
     X, y = synth_batch(B, C, img, img, 1234 + rank, dev)
     net.train()
+    # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
+    # HIP graph and every later call is a replay
+    runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2, use_graph=not args.no_graph)
 
     def step():
-        out = net(X)
-        l = crit(out, y)
-        opt.zero_grad(set_to_none=True)
-        l.mean().backward()
-        reducer.finish()
-        opt.step()
-        return l
+        return runner(X, y)
 
     log(f"model ready: {args.arch} E={E} {img}x{img} B={B}/GPU {args.dtype}; warmup {args.warmup}")
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 0 if args.no_graph else 4)):
         l = step()
         if rank == 0:
             torch.cuda.synchronize()
@@ -147,16 +147,24 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    if not args.no_kernel_events:
-        K.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
     fence()
     dt = time.perf_counter() - t0
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    prof, K.PROFILE = K.PROFILE, None
     loss_val = float(last.item())
+    # per-kernel HIP-event timing for the roofline: graph replays cannot be bracketed kernel by
+    # kernel, so the same step runs eagerly (identical kernels / shapes) right after the timed region
+    prof = None
+    prof_steps = 0
+    if not args.no_kernel_events and rank == 0 or (not args.no_kernel_events and world > 1):
+        K.PROFILE = []
+        for _ in range(args.roofline_steps):
+            runner._eager(X, y)
+            prof_steps += 1
+        torch.cuda.synchronize()
+        prof, K.PROFILE = K.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,8 +187,9 @@ def main():
                     if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": fl / sec / 1e12 /
                     (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
                     "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
-                    "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / args.steps * 1e3,
-                                     "launches_per_step": v[2] / args.steps} for k, v in fam.items()},
+                    "measured": f"HIP events around every launch, {prof_steps} eager steps after the timed region",
+                    "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / prof_steps * 1e3,
+                                     "launches_per_step": v[2] / prof_steps} for k, v in fam.items()},
                     "whole_step_tflops": value / world * flop_img / 1e12}
         line = {"metric": "images/sec at 513x513 fwd+bwd+SGD step (early-exit DeepLabV3 training)",
                 "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,6 +198,7 @@ def main():
                 "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
                                        f"per-exit CE (sum), SGD momentum 0.9 wd 5e-4",
                            "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
+                           "hip_graph": not args.no_graph,
                            "flop_per_image": flop_img, "loss_last_step": loss_val},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -532,11 +532,13 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finalise
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long long n, float p, uint64_t seed) {
+__global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long long n, float p, uint64_t seed0,
+                                                      const long long* __restrict__ step_dev) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long chunks = n / EPC;
     const float keep_scale = 1.f / (1.f - p);
     const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const uint64_t seed = seed0 + (step_dev ? (uint64_t)step_dev[0] * 0xA24BAED4963EE407ull : 0ull);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < chunks;
          i += (long long)gridDim.x * blockDim.x) {
         Vec<T> v = ld16(x + i * EPC);
@@ -962,7 +964,8 @@ extern "C" int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW
     return EESEG_OK;
 }
 
-extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step_dev,
+                             int dtype, void* stream) {
     EESEG_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f, EESEG_ERR_ARG, "dropout: bad argument");
     const int epc = 16 / eeseg_dtype_size(dtype);
     EESEG_CHECK(n % epc == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, EESEG_ERR_ARG,
@@ -971,10 +974,10 @@ extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_
     const int g = ew_grid(n / epc);
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long long)n,
-                           p, seed);
+                           p, seed, (const long long*)step_dev);
     else
         hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, (long long)n, p,
-                           seed);
+                           seed, (const long long*)step_dev);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

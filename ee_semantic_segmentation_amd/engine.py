@@ -33,6 +33,10 @@ class Config:
         self.group = None
         self.dropout_seed = 0x5EED
         self._drop_calls = 0
+        self.arena = None                    # GradArena: parameter gradients written in place
+        self.accumulate = False              # arena mode: add to the stored gradients instead of overwriting
+        self.step_counter = None             # device int64[1]; lets a captured graph draw fresh dropout masks
+        self.on_unit_done = None             # callable(unit_id): gradient bucket scheduling (GradReducer)
 
     def world(self):
         return dist.get_world_size(self.group) if (self.sync_bn and dist.is_initialized()) else 1
@@ -40,6 +44,114 @@ class Config:
     def next_seed(self):
         self._drop_calls += 1
         return (self.dropout_seed * 0x9E3779B97F4A7C15 + self._drop_calls) & (2 ** 63 - 1)
+
+    def step_dev(self, device):
+        if self.step_counter is None or self.step_counter.device != device:
+            self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
+        return self.step_counter
+
+    def end_step(self):
+        """Advance the device-side step counter (captured into training graphs)."""
+        if self.step_counter is not None:
+            self.step_counter.add_(1)
+
+    def gview(self, param):
+        return None if self.arena is None else self.arena.kernel_view.get(param)
+
+    def unit_done(self, module):
+        if self.on_unit_done is not None:
+            uid = module.__dict__.get("_eeseg_unit")
+            if uid is not None:
+                self.on_unit_done(uid)
+
+
+class GradArena:
+    """One flat fp32 buffer holding every parameter gradient of a network.
+
+    ``p.grad`` of each parameter is a view into it and the backward kernels write
+    there directly (conv weight gradients in KRSC = the channels_last parameter
+    layout, BatchNorm (dbeta, dgamma) as one [2,C] pair, the class-padded classifier
+    rows).  Units (stem, bottlenecks, heads) are laid out in REVERSE forward order, so
+    the arena fills front to back during backward and data-parallel buckets are plain
+    slices of it: no flatten / unflatten copies, static addresses for HIP-graph capture.
+    """
+
+    def __init__(self, net):
+        units = []
+        for i, sec in enumerate(net.base_model):
+            mods = list(sec)
+            j = 0
+            if mods and type(mods[0]).__name__ == "Conv2d":
+                units.append(("stem", sec, [(mods[0].weight, "stem"), (mods[1], "bn")]))
+                j = 4
+            for m in mods[j:]:
+                units.append(("block", m, self._block_entries(m)))
+            head = net.branches[i] if i < len(net.branches) else net.classifier
+            units.append(("head", head, self._head_entries(head)))
+        units.reverse()
+        dev = next(net.parameters()).device
+        off = 0
+        plan = []
+        self.unit_ranges = []
+        for uid, (kind, mod, entries) in enumerate(units):
+            start = off
+            mod.__dict__["_eeseg_unit"] = uid
+            for obj, what in entries:
+                if what == "bn":
+                    n = 2 * obj.weight.numel()
+                elif what == "cls_w":
+                    n = CPAD * obj.shape[1]
+                elif what == "cls_b":
+                    n = CPAD
+                else:
+                    n = obj.numel()
+                n_pad = (n + 3) // 4 * 4
+                plan.append((obj, what, off, n))
+                off += n_pad
+            self.unit_ranges.append((start, off))
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.kernel_view = {}          # param (or bn module) -> tensor the kernels write
+        for obj, what, o, n in plan:
+            seg = self.flat[o:o + n]
+            if what == "bn":
+                c = obj.weight.numel()
+                pair = seg.view(2, c)
+                self.kernel_view[obj] = pair
+                obj.bias.grad = pair[0]
+                obj.weight.grad = pair[1]
+            elif what == "cls_w":
+                co, ci = obj.shape[0], obj.shape[1]
+                self.kernel_view[obj] = seg.view(CPAD, 1, 1, ci)
+                obj.grad = seg[:co * ci].view(co, 1, 1, ci).permute(0, 3, 1, 2)
+            elif what == "cls_b":
+                self.kernel_view[obj] = seg
+                obj.grad = seg[:obj.numel()]
+            else:                      # conv weight (incl. stem), stored channels_last = KRSC
+                co, ci, r, s_ = obj.shape
+                if not (obj.is_contiguous(memory_format=torch.channels_last) or (r == 1 and s_ == 1)):
+                    raise RuntimeError("GradArena needs channels_last conv weights")
+                kv = seg.view(co, r, s_, ci)
+                self.kernel_view[obj] = kv
+                obj.grad = kv.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _block_entries(b):
+        e = [(b.conv1.weight, "w"), (b.bn1, "bn"), (b.conv2.weight, "w"), (b.bn2, "bn"), (b.conv3.weight, "w"),
+             (b.bn3, "bn")]
+        if b.downsample is not None:
+            e += [(b.downsample[0].weight, "w"), (b.downsample[1], "bn")]
+        return e
+
+    @staticmethod
+    def _head_entries(h):
+        e = []
+        aspp = h[0]
+        for seq in aspp.convs:
+            conv, bn = (seq[1], seq[2]) if type(seq).__name__ == "ASPPPooling" else (seq[0], seq[1])
+            e += [(conv.weight, "w"), (bn, "bn")]
+        e += [(aspp.project[0].weight, "w"), (aspp.project[1], "bn"), (h[1].weight, "w"), (h[2], "bn"),
+              (h[4].weight, "cls_w"), (h[4].bias, "cls_b")]
+        return e
 
 
 def packed(conv, dtype, cout_pad=None):
@@ -87,28 +199,47 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
 
 
 def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):
-    """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta)."""
+    """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
+    parameter gradients are None in arena mode (written in place)."""
     x, c, y, mi, count, relu = st
-    sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu)
-    dbeta, dgamma = sums[0], sums[1]
+    pair = cfg.gview(bn)
+    if pair is not None and cfg.accumulate:
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu)
+        pair.add_(sums)
+    else:
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair)
+    dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
     if cfg.world() > 1:
-        dbeta, dgamma = dbeta.clone(), dgamma.clone()      # parameter grads stay local (DP averages them)
+        if pair is None:
+            dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
+        sums = sums.clone() if pair is not None else sums
         _allreduce(cfg, sums)
     dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres)
+    gv = cfg.gview(conv.weight)
     if x_is_col:
         dw = K.conv_wgrad(x, dc, 1, 1)
-        cout, _, r, s_ = conv.weight.shape
-        cin = conv.weight.shape[1]
-        dwp = dw.view(cout, -1)[:, :r * s_ * cin].reshape(cout, r, s_, cin).permute(0, 3, 1, 2)
-        return None, dres, dwp, dgamma, dbeta
+        cout, cin, r, s_ = conv.weight.shape
+        dwk = dw.view(cout, -1)[:, :r * s_ * cin]
+        if gv is not None:
+            g2 = gv.view(cout, r * s_ * cin)
+            if cfg.accumulate:
+                g2.add_(dwk)
+            else:
+                g2.copy_(dwk)
+            return None, dres, None, dgamma, dbeta
+        return None, dres, dwk.reshape(cout, r, s_, cin).permute(0, 3, 1, 2), dgamma, dbeta
     s, p, d = _geom(conv)
     R, S = conv.weight.shape[2], conv.weight.shape[3]
-    dw = K.conv_wgrad(x, dc, R, S, s, p, d)
+    if gv is not None:
+        K.conv_wgrad(x, dc, R, S, s, p, d, out=gv, accumulate=cfg.accumulate)
+        dwp = None
+    else:
+        dwp = K.conv_wgrad(x, dc, R, S, s, p, d).permute(0, 3, 1, 2)
     dx = None
     if need_dx:
         _, wb = packed(conv, dc.dtype)
         dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
-    return dx, dres, dw.permute(0, 3, 1, 2), dgamma, dbeta
+    return dx, dres, dwp, dgamma, dbeta
 
 
 def conv_bn_eval(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False):
@@ -200,6 +331,7 @@ def bottleneck_bwd(cfg, state, dout, blk):
         dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_accum=dres)
         extra = []
     grads = [dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3] + extra
+    cfg.unit_done(blk)
     return dx, grads
 
 
@@ -236,7 +368,7 @@ def head_fwd(cfg, x, head, train):
         pdrop = proj[3].p
         if pdrop > 0:
             seed = cfg.next_seed()
-            pr_d = K.dropout(pr, pdrop, seed)
+            pr_d = K.dropout(pr, pdrop, seed, cfg.step_dev(pr.device))
         else:
             pr_d = pr
         q, stq = conv_bn_fwd(cfg, pr_d, head[1], head[2], True)
@@ -270,8 +402,17 @@ def head_bwd(cfg, state, dlogits, head):
     cls = head[4]
     ncls = cls.weight.shape[0]
     # classifier
-    dbias = K.colsum(dlogits)[:ncls]
-    dwc = K.conv_wgrad(q32, dlogits, 1, 1)[:ncls].permute(0, 3, 1, 2)
+    gvb, gvw = cfg.gview(cls.bias), cfg.gview(cls.weight)
+    if gvw is not None:
+        if cfg.accumulate:
+            gvb.add_(K.colsum(dlogits))
+        else:
+            K.colsum(dlogits, out=gvb)
+        K.conv_wgrad(q32, dlogits, 1, 1, out=gvw, accumulate=cfg.accumulate)
+        dbias = dwc = None
+    else:
+        dbias = K.colsum(dlogits)[:ncls]
+        dwc = K.conv_wgrad(q32, dlogits, 1, 1)[:ncls].permute(0, 3, 1, 2)
     _, wb = packed(cls, torch.float32, CPAD)
     dq = K.conv_dgrad(dlogits, wb, (h, w))
     if cfg.compute_dtype != torch.float32:
@@ -279,7 +420,7 @@ def head_bwd(cfg, state, dlogits, head):
     # 3x3 conv + BN + ReLU
     dpr_d, _, dw3, dg3, db3 = conv_bn_bwd(cfg, stq, dq, head[1], head[2])
     proj = aspp.project
-    dpr = K.dropout(dpr_d, proj[3].p, seed) if seed is not None else dpr_d
+    dpr = K.dropout(dpr_d, proj[3].p, seed, cfg.step_dev(dpr_d.device)) if seed is not None else dpr_d
     dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
     grads_convs = []
     dx = None
@@ -294,4 +435,5 @@ def head_bwd(cfg, state, dlogits, head):
     K.broadcast_hw(dg_.view(N, cin), dx, scale=1.0 / (h * w), accumulate=True)
     grads_convs += [dwp, dgp, dbp]
     grads = grads_convs + [dwj, dgj, dbj, dw3, dg3, db3, dwc, dbias]
+    cfg.unit_done(head)
     return dx, grads

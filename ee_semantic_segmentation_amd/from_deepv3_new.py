@@ -276,6 +276,14 @@ class branchyDeepv3(nn.Module):
     def macs(self, H, W=None):
         return model_macs(self, H, W or H)
 
+    def enable_grad_arena(self, accumulate=False):
+        """Keep every parameter gradient in one flat buffer that the backward kernels write
+        directly (static addresses: needed for HIP-graph capture and zero-copy DP buckets).
+        Call after .to(device).  Use this package's SGD (its zero_grad keeps the views)."""
+        self.cfg.arena = E.GradArena(self)
+        self.cfg.accumulate = accumulate
+        return self.cfg.arena
+
     # -- forward ------------------------------------------------------------------
     def forward_lowres(self, X):
         """Low-res logits of every exit, shallow -> deep (final exit last)."""

@@ -290,19 +290,22 @@ def channel_stats(x):
     return sums
 
 
-def colsum(x):
+def colsum(x, out=None):
     rows, Cc, ldx = rows_ld(x)
-    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and out.numel() == Cc and out.dtype == torch.float32
     ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
     check(lib().eeseg_colsum(_p(x), ldx, rows, Cc, _p(out), _dt(x), _p(ws), ws.numel(), _stream()), "eeseg_colsum")
     return out
 
 
-def bn_bwd_reduce(dy, y, x, mean_invstd, relu):
+def bn_bwd_reduce(dy, y, x, mean_invstd, relu, out=None):
     rows, Cc, lddy = rows_ld(dy)
     _, _, ldx = rows_ld(x)
     ldy = rows_ld(y)[2] if y is not None else 0
-    sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    sums = out if out is not None else torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    assert sums.is_contiguous() and sums.shape == (2, Cc) and sums.dtype == torch.float32
     ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
     check(lib().eeseg_bn_bwd_reduce(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), rows, Cc, int(relu),
                                     _p(sums), _dt(x), _p(ws), ws.numel(), _stream()), "eeseg_bn_bwd_reduce")
@@ -371,11 +374,11 @@ def broadcast_hw(x, out, scale=1.0, accumulate=False):
     return out
 
 
-def dropout(x, p, seed):
+def dropout(x, p, seed, step_dev=None):
     assert x.is_contiguous()
     y = torch.empty_like(x)
-    check(lib().eeseg_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _dt(x), _stream()),
-          "eeseg_dropout")
+    check(lib().eeseg_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _p(step_dev), _dt(x),
+                              _stream()), "eeseg_dropout")
     return y
 
 

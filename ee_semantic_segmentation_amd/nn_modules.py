@@ -111,9 +111,9 @@ def _needs_grad(*tensors):
 # ----------------------------------------------------------------- stem ------
 class _StemFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, w, g, b, conv, bn, cfg):
+    def forward(ctx, img, w, g, b, conv, bn, cfg, section):
         out, st = E.stem_fwd(cfg, img, conv, bn, True)
-        ctx.st, ctx.mods, ctx.cfg = st, (conv, bn), cfg
+        ctx.st, ctx.mods, ctx.cfg, ctx.section = st, (conv, bn), cfg, section
         return out
 
     @staticmethod
@@ -121,12 +121,13 @@ class _StemFn(torch.autograd.Function):
         conv, bn = ctx.mods
         dw, dg, db = E.stem_bwd(ctx.cfg, ctx.st, dout.contiguous(), conv, bn)
         ctx.st = None
-        return None, dw, dg, db, None, None, None
+        ctx.cfg.unit_done(ctx.section)
+        return None, dw, dg, db, None, None, None, None
 
 
-def run_stem(cfg, img, conv, bn, train):
+def run_stem(cfg, img, conv, bn, train, section=None):
     if train and _needs_grad(conv.weight, bn.weight, bn.bias):
-        return _StemFn.apply(img, conv.weight, bn.weight, bn.bias, conv, bn, cfg)
+        return _StemFn.apply(img, conv.weight, bn.weight, bn.bias, conv, bn, cfg, section)
     with torch.no_grad():
         return E.stem_fwd(cfg, img, conv, bn, train)[0]
 
@@ -274,7 +275,7 @@ class Section(nn.Sequential):
         mods = list(self)
         i = 0
         if mods and isinstance(mods[0], Conv2d):
-            x = run_stem(cfg, x, mods[0], mods[1], self.training and mods[1].training)
+            x = run_stem(cfg, x, mods[0], mods[1], self.training and mods[1].training, self)
             i = 4
         for m in mods[i:]:
             x = m(x)

@@ -13,6 +13,13 @@ class SGD(torch.optim.Optimizer):
             raise ValueError("invalid SGD hyper-parameter")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.grad_scale = grad_scale
+        self._tables = {}          # group index -> (key, table, sizes, lrs, lr value)
+        self.static_grads = False  # set by GradArena users: zero_grad must keep the .grad views
+
+    def zero_grad(self, set_to_none=True):
+        if self.static_grads:
+            return                 # arena gradients are overwritten by the next backward
+        super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -20,7 +27,7 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
@@ -35,24 +42,39 @@ class SGD(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)
                     first = True
                 g = p.grad
-                if g.stride() != p.stride():          # kernels index raw memory: layouts must agree
-                    g = g.contiguous(memory_format=torch.preserve_format)
-                    if g.stride() != p.stride():
-                        g = torch.empty_like(p).copy_(p.grad)
-                    p.grad = g
+                if g.stride() != p.stride() and p.numel() > 1:      # kernels index raw memory
+                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                    g2.copy_(g)
+                    p.grad = g = g2
                 if g.dtype != torch.float32 or p.dtype != torch.float32:
                     raise _lib.EesegError("fused SGD expects fp32 master parameters and gradients")
-                rows.append([p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr()])
+                rows.append((p.data_ptr(), g.data_ptr(), st["momentum_buffer"].data_ptr()))
                 sizes.append(p.numel())
-            table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
-            sz = torch.tensor(sizes, dtype=torch.int64).to(dev, non_blocking=True)
-            lrs = torch.full((len(ps),), float(group["lr"]), dtype=torch.float32, device=dev)
+            key = tuple(rows)
+            cached = self._tables.get(gi)
+            if cached is None or cached[0] != key:
+                table = torch.tensor(rows, dtype=torch.int64).to(dev)
+                sz = torch.tensor(sizes, dtype=torch.int64).to(dev)
+                lrs = torch.full((len(ps),), float(group["lr"]), dtype=torch.float32, device=dev)
+                cached = [key, table, sz, lrs, float(group["lr"])]
+                self._tables[gi] = cached
+            elif cached[4] != float(group["lr"]):
+                cached[3].fill_(float(group["lr"]))
+                cached[4] = float(group["lr"])
+            _, table, sz, lrs, _ = cached
             rc = _lib.lib().eeseg_sgd_step(C.c_void_p(table.data_ptr()), C.c_void_p(sz.data_ptr()),
                                            C.c_void_p(lrs.data_ptr()), len(ps), float(group["momentum"]),
                                            float(group["weight_decay"]), float(self.grad_scale), int(first),
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "eeseg_sgd_step")
-            # keep the tables alive until the launch has consumed them
-            self._keep = getattr(self, "_keep", [])[-8:] + [(table, sz, lrs)]
         engine.bump_weights_epoch()
         return loss
+
+    def sync_lr(self):
+        """Push changed learning rates to the device tables (call after scheduler.step()
+        when the step itself is replayed from a captured graph)."""
+        for gi, group in enumerate(self.param_groups):
+            cached = self._tables.get(gi)
+            if cached is not None and cached[4] != float(group["lr"]):
+                cached[3].fill_(float(group["lr"]))
+                cached[4] = float(group["lr"])

@@ -14,6 +14,8 @@ all-reduced inside the respective layers.
 import torch
 import torch.distributed as dist
 
+from . import engine
+
 
 def _flat_view(t):
     """1-D view of a dense tensor in its PHYSICAL element order (no copy)."""
@@ -97,3 +99,115 @@ def broadcast_parameters(module, src=0, group=None):
         for t in list(module.parameters()) + list(module.buffers()):
             flat = _flat_view(t.data)
             dist.broadcast(flat, src, group=group)
+
+
+class ArenaReducer:
+    """Gradient all-reduce over slices of a GradArena (engine.GradArena).
+
+    The arena is laid out in backward completion order, so bucket k is simply
+    ``flat[b_k : b_{k+1}]``; it is launched (async, on RCCL's stream) as soon as the
+    last unit it covers has finished its backward, overlapping with the rest of
+    backward.  No flatten / unflatten copies."""
+
+    def __init__(self, net, bucket_bytes=64 << 20, group=None, average=True):
+        self.cfg, self.group, self.average = net.cfg, group, average
+        self.arena = net.cfg.arena
+        if self.arena is None:
+            raise RuntimeError("call net.enable_grad_arena() first")
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = []            # (first unit, last unit, start, end)
+        u0, start = 0, 0
+        for u, (a, b) in enumerate(self.arena.unit_ranges):
+            if (b - start) * 4 >= bucket_bytes or u == len(self.arena.unit_ranges) - 1:
+                self.buckets.append((u0, u, start, b))
+                u0, start = u + 1, b
+        self._done = set()
+        self._next = 0
+        self._works = []
+        if self.world > 1:
+            self.cfg.on_unit_done = self._unit_done
+
+    def _unit_done(self, uid):
+        self._done.add(uid)
+        while self._next < len(self.buckets):
+            u0, u1, a, b = self.buckets[self._next]
+            if not all(u in self._done for u in range(u0, u1 + 1)):
+                break
+            self._launch(a, b)
+            self._next += 1
+
+    def _launch(self, a, b):
+        seg = self.arena.flat[a:b]
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg, op))
+
+    def finish(self):
+        if self.world == 1:
+            return
+        while self._next < len(self.buckets):       # units that produced no gradient this step
+            _, _, a, b = self.buckets[self._next]
+            self._launch(a, b)
+            self._next += 1
+        for work, seg, op in self._works:
+            work.wait()
+            if self.average and op == dist.ReduceOp.SUM:
+                seg.div_(self.world)
+        self._done.clear()
+        self._next = 0
+        self._works = []
+
+
+class GraphedTrainStep:
+    """One training step (forward, loss, backward, gradient all-reduce, SGD step) captured
+    into a HIP graph and replayed: ~1000 kernel launches per step leave the Python
+    critical path.  Needs the gradient arena (static gradient addresses) and this
+    package's SGD.  The first `warmup` calls run eagerly (allocator warm-up, momentum
+    buffer initialisation), the next call captures, later calls replay."""
+
+    def __init__(self, net, criterion, optimizer, reducer=None, warmup=2, use_graph=True):
+        self.net, self.criterion, self.opt, self.reducer = net, criterion, optimizer, reducer
+        self.warmup, self.use_graph = warmup, use_graph
+        self.calls = 0
+        self.graph = None
+        self.X = self.y = self.loss = None
+        if net.cfg.arena is not None:
+            optimizer.static_grads = True
+        self._bns = [m for m in net.modules() if type(m).__name__ == "BatchNorm2d"]
+
+    def _eager(self, X, y):
+        out = self.net(X)
+        loss = self.criterion(out, y)
+        self.opt.zero_grad(set_to_none=True)
+        loss.mean().backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        self.net.cfg.end_step()
+        return loss.detach()
+
+    def __call__(self, X, y):
+        self.calls += 1
+        if not self.use_graph or self.calls <= self.warmup:
+            return self._eager(X, y)
+        if self.graph is None:
+            if self.net.cfg.arena is None:
+                raise RuntimeError("graph capture needs net.enable_grad_arena()")
+            self.X, self.y = X.clone(), y.clone()
+            before = [b._pending_batches for b in self._bns]
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager(self.X, self.y)
+            self._active = [b for b, n in zip(self._bns, before) if b._pending_batches != n]
+            for b, n in zip(self._bns, before):
+                b._pending_batches = n              # capture itself does not run the kernels
+        if X.data_ptr() != self.X.data_ptr():
+            self.X.copy_(X, non_blocking=True)
+        if y.data_ptr() != self.y.data_ptr():
+            self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        for b in self._active:
+            b._pending_batches += 1
+        engine.bump_weights_epoch()      # eager code after a replay must re-pack the updated weights
+        return self.loss

@@ -147,9 +147,12 @@ int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float sc
  * and accumulate = 1 it is the backward of the average pool) */
 int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW, int C, float scale, int accumulate,
                        int dtype, void* stream);
-/* Dropout(p) with a counter-based hash RNG: keep iff hash(seed, index) >= p;
- * kept values are scaled by 1/(1-p).  Backward = the same call on dy. */
-int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* Dropout(p) with a counter-based hash RNG: keep iff hash(seed', index) >= p with
+ * seed' = seed + K*step_dev[0] (step_dev: optional device step counter, so a captured
+ * HIP graph draws a fresh mask every replay); kept values are scaled by 1/(1-p).
+ * Backward = the same call on dy. */
+int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step_dev, int dtype,
+                  void* stream);
 int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, int64_t n, void* stream);
 /* y[i] += x[i] (gradient accumulation at residual joins) */
 int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream);

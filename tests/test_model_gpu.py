@@ -251,3 +251,45 @@ def test_block_level_gradients_strict():
     rp = dict(rh.named_parameters())
     for k, p in head.named_parameters():
         assert _rel(p.grad, rp[k].grad) < 2e-3, k
+
+
+def test_graphed_arena_step_matches_eager():
+    """GradArena + HIP-graph replay reproduce the plain eager autograd training loop."""
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    from ee_semantic_segmentation_amd.optim import SGD
+    from ee_semantic_segmentation_amd.parallel import GraphedTrainStep
+    C, B, img, steps = 21, 2, 65, 5
+    X, y = _inputs(B, C, img, img)
+    Xd, yd = X.to(DEV), y.to(DEV)
+    crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=2)
+    runs = []
+    for mode in ("eager", "graph"):
+        net, _ = _pair("deeplabv3_resnet50", 1, img)
+        net.train()
+        net.fused_outputs = True
+        opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+        losses = []
+        if mode == "eager":
+            for _ in range(steps):
+                l = crit(net(Xd), yd)
+                opt.zero_grad()
+                l.mean().backward()
+                opt.step()
+                losses.append(l.item())
+        else:
+            net.enable_grad_arena()
+            runner = GraphedTrainStep(net, crit, opt, warmup=2)
+            for _ in range(steps):
+                losses.append(float(runner(Xd, yd).item()))
+            assert runner.graph is not None
+        sd = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
+        runs.append((losses, sd))
+    (l0, s0), (l1, s1) = runs
+    assert np.allclose(l0, l1, rtol=2e-3, atol=1e-4), (l0, l1)
+    assert l0[-1] < l0[0]
+    for k in s0:
+        if k.endswith("num_batches_tracked"):
+            assert int(s0[k]) == int(s1[k]) == steps, k
+    # parameters after 5 chaotic steps: same scale of agreement as two eager runs would have
+    worst = max(_rel(s1[k], s0[k]) for k in s0 if k.endswith("weight") and s0[k].dim() == 4)
+    assert worst < 5e-2, worst
