@@ -39,6 +39,7 @@ _vp, _i, _i64, _f, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_dou
 SIGNATURES = {
     "eeseg_last_error": (C.c_char_p, []),
     "eeseg_version": (_i, []),
+    "eeseg_set_option": (_i, [_i, _i]),
     "eeseg_conv_stats_tiles": (_i, [_i, _i, _i]),
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),

@@ -60,7 +60,7 @@ __device__ __forceinline__ bool map_coord(int base, int t, int tstep, int sdiv, 
 constexpr int BM = 128;     // pixels per tile
 constexpr int ROWB = 128;   // bytes of K per LDS row
 
-template <typename T, int BN>
+template <typename T, int BN, int PIPE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     constexpr int EPK = ROWB / (int)sizeof(T);        // K elements per step
     constexpr int WAVES_C = BN / 64;                  // waves along cout
@@ -142,40 +142,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    i32x4 ra[4], rwv[WCH];
-    int tap = -1, c0 = 0;
+    i32x4 ra0[4], rw0[WCH], ra1[4], rw1[WCH];     // two staging register sets (tiles k+1 and k+2)
+    // Gather offsets are recomputed only when the filter tap changes; the channel step inside a
+    // tap goes through the buffer instruction's scalar offset (no per-K-step VALU address math).
+    // An out-of-image row keeps voffset = EESEG_OOB: voffset + soffset stays out of range -> zeros.
+    uint32_t voffA[4], voffW[WCH];
     unsigned rest = tapmask;
+    int ci = kc_steps - 1;      // forces a tap advance on the first next_tile()
 
-    auto next_tile = [&]() {   // block-uniform iterator over (valid tap, channel step)
-        if (tap < 0 || c0 + EPK >= p.Cin) {
-            tap = __ffs(rest) - 1;
-            rest &= rest - 1;
-            c0 = 0;
-        } else {
-            c0 += EPK;
-        }
-    };
-    auto load_tile = [&]() {
+    auto set_tap = [&](int tap) {
         const int r = tap / p.S, s = tap - r * p.S;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int hi = 0, wi = 0;
             const bool ok = map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) &&
                             map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi);
-            const uint32_t off = ok ? (uint32_t)(((nb[j] + hi * p.Win + wi) * p.Cin + c0) * (int)sizeof(T) + lchunk * 16)
-                                    : EESEG_OOB;
-            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+            voffA[j] = ok ? (uint32_t)(((nb[j] + hi * p.Win + wi) * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
         }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
             const int co = n0 + lrow + 32 * j;
-            const uint32_t off = (co < p.Cout)
-                                     ? (uint32_t)(((co * taps + tap) * p.Cin + c0) * (int)sizeof(T) + lchunk * 16)
-                                     : EESEG_OOB;
-            rwv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)off, 0, 0);
+            voffW[j] = (co < p.Cout) ? (uint32_t)(((co * taps + tap) * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto next_tile = [&]() {   // block-uniform iterator over (valid tap, channel step)
+        if (++ci >= kc_steps) {
+            ci = 0;
+            if (rest) {
+                const int tap = __ffs(rest) - 1;
+                rest &= rest - 1;
+                set_tap(tap);
+            } else {           // past the last tile: every load becomes an out-of-range (zero, no traffic) load
+#pragma unroll
+                for (int j = 0; j < 4; ++j) voffA[j] = EESEG_OOB;
+#pragma unroll
+                for (int j = 0; j < WCH; ++j) voffW[j] = EESEG_OOB;
+            }
+        }
+    };
+    auto load_tile = [&](i32x4 (&ra)[4], i32x4 (&rwv)[WCH]) {
+        const int soff = ci * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voffA[j], soff, 0);
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) rwv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)voffW[j], soff, 0);
+    };
+    auto store_tile = [&](int buf, const i32x4 (&ra)[4], const i32x4 (&rwv)[WCH]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = lrow + 32 * j;
@@ -191,19 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
     const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
 
-    if (nk > 0) {
-        next_tile();
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool has_next = kt + 1 < nk;
-        if (has_next) {
-            next_tile();
-            load_tile();
-        }
+    auto compute = [&](int cur) {
         const char* xa = sX + cur * BM * ROWB + (wp * 32 * TJ + fr) * ROWB;
         const char* wa = sW + cur * BN * ROWB + (wc * 64 + fr) * ROWB;
 #pragma unroll
@@ -219,9 +219,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
         }
-        if (has_next) store_tile(cur ^ 1);
+    };
+
+    // Pipeline: LDS[cur] = tile k, set A = tile k+1 (in flight / landed), set B <- tile k+2 issued
+    // before computing tile k, so every global load has two compute phases to land.  Loads and
+    // LDS stores are unconditional (tiles past the end are out-of-range zero loads) so the
+    // compiler's counted s_waitcnt vmcnt leaves the 8 newest loads in flight.
+    if constexpr (PIPE == 2) {
+        next_tile();
+        load_tile(ra0, rw0);
+        store_tile(0, ra0, rw0);
+        next_tile();
+        load_tile(ra0, rw0);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = 0; kt < nk; kt += 2) {
+            next_tile();
+            load_tile(ra1, rw1);
+            compute(cur);
+            store_tile(cur ^ 1, ra0, rw0);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            next_tile();
+            load_tile(ra0, rw0);
+            compute(cur ^ 1);
+            store_tile(cur, ra1, rw1);
+            __syncthreads();
+        }
+    } else {   // PIPE == 1: one tile of prefetch (fewer registers)
+        next_tile();
+        load_tile(ra0, rw0);
+        store_tile(0, ra0, rw0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            next_tile();
+            load_tile(ra0, rw0);
+            compute(cur);
+            store_tile(cur ^ 1, ra0, rw0);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // ---- epilogue 1: acc -> (scale, shift) -> LDS staging [pixel][cout] --------
@@ -340,15 +378,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+int g_conv_pipe = 2;     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
+
 template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3(grid), dim3(256), 0, st, p);
+    if (g_conv_pipe == 2)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2>), dim3(grid), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1>), dim3(grid), dim3(256), 0, st, p);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
 
 }  // namespace
+
+extern "C" int eeseg_set_option(int key, int value) {
+    if (key == EESEG_OPT_CONV_PIPE && (value == 1 || value == 2)) {
+        g_conv_pipe = value;
+        return EESEG_OK;
+    }
+    eeseg_set_error("set_option: unknown key %d / value %d", key, value);
+    return EESEG_ERR_ARG;
+}
 
 extern "C" int eeseg_conv_stats_tiles(int N, int Hout, int Wout) {
     const long long M = (long long)N * Hout * Wout;

@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     constexpr int KP = 128 / ES;            // pixels per K step (64 / 32)
     constexpr int ROWW = 128 * ES;          // bytes per LDS row = 128 channels
     constexpr int CPRW = ROWW / 16;         // 16-byte chunks per row (16 / 32)
-    constexpr int RPP = 256 / CPRW;         // rows per load pass (16 / 8)
     constexpr int EPC = 16 / ES;
     constexpr int TILE = KP * ROWW;         // 16 KiB
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
@@ -47,54 +46,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     const int pe = min(p.M, ps + p.chunk);
     const int nk = (pe > ps) ? (pe - ps + KP - 1) / KP : 0;
 
-    const int c = tid % CPRW, rbase = tid / CPRW;
-    // running pixel coordinates of my 4 rows
-    int pn[4], ph[4], pw[4], pm[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = ps + rbase + j * RPP;
-        pm[j] = m;
-        const int n = m / p.HWout;
-        const int rem = m - n * p.HWout;
-        ph[j] = rem / p.Wout;
-        pw[j] = rem - ph[j] * p.Wout;
-        pn[j] = n;
-    }
+    // one pixel row per thread (KP rows x TPR threads), 4 chunks interleaved over the row's threads
+    // (chunk = t + TPR*i: each load/LDS-store instruction covers a contiguous run per row, conflict
+    // free): a single running (n, ho, wo) and one validity test per K step.
+    constexpr int TPR = CPRW / 4;            // threads per row (4 bf16 / 8 f32); 256 / TPR == KP rows
+    const int lrow = tid / TPR;
+    const int cb = tid % TPR;                // chunks cb + TPR*i, i = 0..3
+    int pm = ps + lrow;
+    int pn = pm / p.HWout;
+    int prem = pm - pn * p.HWout;
+    int ph = prem / p.Wout;
+    int pw = prem - ph * p.Wout;
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
-    const bool co_ok = (co0 + c * EPC) < p.Cout;
-    const bool ci_ok = (ci0 + c * EPC) < p.Cin;
+    // per-chunk channel validity (tails of Cout / Cin tiles)
+    bool co_ok[4], ci_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        co_ok[i] = (co0 + (cb + TPR * i) * EPC) < p.Cout;
+        ci_ok[i] = (ci0 + (cb + TPR * i) * EPC) < p.Cin;
+    }
 
     i32x4 rdyv[4], rxv[4];
     auto load_tile = [&]() {
+        const bool in = pm < pe;
+        const uint32_t based = in ? (uint32_t)((pm * p.lddy + co0) * ES + cb * 16) : EESEG_OOB;
+        const int hi = ph * p.stride + dh, wi = pw * p.stride + dwv;
+        const bool ok = in && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+        const uint32_t basex = ok ? (uint32_t)((((pn * p.Hin + hi) * p.Win + wi) * p.Cin + ci0) * ES + cb * 16)
+                                  : EESEG_OOB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = pm[j] < pe;
-            const uint32_t offd = (in && co_ok) ? (uint32_t)((pm[j] * p.lddy + co0) * ES + c * 16) : EESEG_OOB;
-            rdyv[j] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)offd, 0, 0);
-            const int hi = ph[j] * p.stride + dh, wi = pw[j] * p.stride + dwv;
-            const bool ok = in && ci_ok && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-            const uint32_t offx = ok ? (uint32_t)((((pn[j] * p.Hin + hi) * p.Win + wi) * p.Cin + ci0) * ES + c * 16)
-                                     : EESEG_OOB;
-            rxv[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)offx, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            rdyv[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)(co_ok[i] ? based + i * (TPR * 16) : EESEG_OOB), 0, 0);
+            rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ci_ok[i] ? basex + i * (TPR * 16) : EESEG_OOB), 0, 0);
         }
     };
     auto advance = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pm[j] += KP;
-            pw[j] += KP;
-            while (pw[j] >= p.Wout) { pw[j] -= p.Wout; ph[j] += 1; }
-            while (ph[j] >= p.Hout) { ph[j] -= p.Hout; pn[j] += 1; }
-        }
+        pm += KP;
+        pw += KP;
+        while (pw >= p.Wout) { pw -= p.Wout; ph += 1; }
+        while (ph >= p.Hout) { ph -= p.Hout; pn += 1; }
     };
     auto store_tile = [&](int buf) {
+        const int sw = (lrow & 3) << 6;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = rbase + j * RPP;
-            const int o = row * ROWW + ((c * 16) ^ ((row & 3) << 6));
-            *reinterpret_cast<i32x4*>(sDY + buf * TILE + o) = rdyv[j];
-            *reinterpret_cast<i32x4*>(sX + buf * TILE + o) = rxv[j];
+        for (int i = 0; i < 4; ++i) {
+            const int o = lrow * ROWW + (((cb + TPR * i) * 16) ^ sw);
+            *reinterpret_cast<i32x4*>(sDY + buf * TILE + o) = rdyv[i];
+            *reinterpret_cast<i32x4*>(sX + buf * TILE + o) = rxv[i];
         }
     };
 

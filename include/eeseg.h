@@ -35,6 +35,10 @@ enum {
 
 const char* eeseg_last_error(void);
 int eeseg_version(void);
+/* tuning switches (process wide).  EESEG_OPT_CONV_PIPE: global-load prefetch depth
+ * of the implicit-GEMM conv kernel, 1 or 2 (default) K-steps. */
+enum { EESEG_OPT_CONV_PIPE = 1 };
+int eeseg_set_option(int key, int value);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision
