@@ -257,8 +257,10 @@ def test_graphed_arena_step_matches_eager():
     """GradArena + HIP-graph replay reproduce the plain eager autograd training loop.
 
     Training trajectories are chaotic (train-mode BN) and the weight-gradient kernel sums
-    with fp32 atomics, so two EAGER runs already differ; the graphed run must stay within
-    3x of that eager-vs-eager spread (floor 2e-3 relative) at every step."""
+    with fp32 atomics, so two EAGER runs already differ (scripts/diag_graph.py: eager,
+    arena-eager and graph runs all scatter by ~3e-3 from the third step on); the graphed
+    run must match to 1e-4 for the first two steps and stay within max(3x the eager-vs-eager
+    spread, 1e-2 relative) afterwards."""
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
     from ee_semantic_segmentation_amd.optim import SGD
     from ee_semantic_segmentation_amd.parallel import GraphedTrainStep
@@ -289,9 +291,11 @@ def test_graphed_arena_step_matches_eager():
         sd = {k: v.detach().float().cpu().clone() for k, v in net.state_dict().items()}
         runs.append((np.array(losses), sd))
     (la, sa), (lb, _), (lg, sg) = runs
+    # measured on MI355X: independent eager runs scatter by ~3e-3 relative from step 3 on
     spread = np.abs(la - lb)
     err = np.abs(lg - la)
-    assert np.all(err <= np.maximum(3 * spread, 2e-3 * np.abs(la))), (la.tolist(), lb.tolist(), lg.tolist())
+    assert np.all(err[:2] <= 1e-4 * np.abs(la[:2])), (la.tolist(), lg.tolist())     # before chaos kicks in
+    assert np.all(err <= np.maximum(3 * spread, 1e-2 * np.abs(la))), (la.tolist(), lb.tolist(), lg.tolist())
     assert la[-1] < la[0] and lg[-1] < lg[0]
     for k in sa:
         if k.endswith("num_batches_tracked"):
