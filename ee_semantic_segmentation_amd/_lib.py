@@ -71,6 +71,8 @@ SIGNATURES = {
     "eeseg_argmax_confusion": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),
+    "eeseg_lovasz_workspace": (_i64, [_i64, _i]),
+    "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _i64, _vp]),
     "eeseg_sgd_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
 }
 

@@ -1,0 +1,159 @@
+"""Train / evaluate orchestration of the reference (deepv3_funcs.py:19-197 ``train_deepv3``,
+:200-279 ``eval_deepv3``) over the HIP path: same ``dts_info`` keys, SGD parameter groups
+(base_model @ base_lr, branches @ lr, classifier @ 1.1*lr; momentum .9, wd 5e-4), poly LR
+schedule, best-checkpoint dict, per-epoch tracker CSV, final test mIoU row appended to
+``./mIoU_{n}_branches_results.csv``.  Fixes: B-1 (``-t`` honoured), B-10 (NameError on a
+second batch size)."""
+import datetime as dttm
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+from pandas import DataFrame
+from torch import optim, utils
+
+from . import from_deepv3_new as dv3
+from .eval_mIoU import mIoU_evaluator
+from .optim import SGD
+from .train_funcs import train
+
+get_metric = {"mIoU": mIoU_evaluator}          # module_variables.py:112
+
+
+def _say(msg, use_file):
+    if use_file:
+        with open(use_file, "a") as f:
+            f.write(msg)
+    else:
+        print(msg)
+
+
+def train_deepv3(net, num_epochs, kwargs):
+    net_id = kwargs.get("name", kwargs.get("net_id"))
+    train_set, val_loader = kwargs["train_set"], kwargs["val_loader"]
+    num_epochs = kwargs["num_epochs"]
+    device = kwargs.get("device", torch.device("cpu"))
+    use_file, res_dir = kwargs.get("use_file"), kwargs["mod_dir"]
+    batch_size = kwargs["batch_sizes"]
+    lr, min_lr, base_lr = kwargs["lr"], kwargs.get("min_lr", 0), kwargs.get("base_lr")
+    freeze_backbone, freeze_from = kwargs.get("freeze_backbone", False), kwargs.get("freeze_from", False)
+    weighted_lr = kwargs.get("weighted_lr", False)
+    patience, loss = kwargs.get("patience"), kwargs["loss"]
+    metrics = [(i, get_metric[i]) for i in kwargs["metrics"]]
+    train_metrics = [(i, get_metric[i]) for i in kwargs["metrics"][:2]]
+    use_scheduler = kwargs.get("use_scheduler")
+    start_from = kwargs.get("start_from")
+    if start_from:
+        start_from = os.path.join(kwargs["main_dir"], start_from)
+    minimize = kwargs.get("minimize", True)
+    n_branches = getattr(net, "n_branches", None)
+
+    net.to(device)
+    params = []
+    if n_branches and base_lr:                                   # deepv3_funcs.py:74-99
+        if freeze_backbone:
+            for p in net.base_model.parameters():
+                p.requires_grad = False
+            if freeze_from:
+                for p in net.branches[freeze_from:].parameters():
+                    p.requires_grad = False
+        else:
+            params.append({"params": net.base_model.parameters(), "lr": base_lr})
+        if weighted_lr:
+            weights = np.linspace(1, 1.2, num=n_branches)
+            params.extend({"params": net.branches[i].parameters(), "lr": lr * weights[i]}
+                          for i in range(len(weights) - 1))
+            params.append({"params": net.classifier.parameters(), "lr": lr * weights[-1]})
+        elif freeze_backbone:
+            br = net.branches[:freeze_from] if freeze_from else net.branches
+            params.append({"params": br.parameters(), "lr": lr})
+            params.append({"params": net.classifier.parameters(), "lr": lr})
+        else:
+            params.append({"params": net.branches.parameters(), "lr": lr})
+            params.append({"params": net.classifier.parameters(), "lr": lr * 1.1})
+        optimizer = SGD(params, lr=lr, momentum=.9, weight_decay=5e-4)
+    else:
+        optimizer = SGD(net.parameters(), lr=lr, momentum=.9, weight_decay=5e-4)
+    if not freeze_backbone and hasattr(net, "enable_grad_arena") and device.type == "cuda":
+        net.enable_grad_arena()
+        net.fused_outputs = True
+
+    _say(f"--> Started training {net_id} (time: {dttm.datetime.now().strftime('%m/%d %H:%M:%S')})\n", use_file)
+    saveat = os.path.join(res_dir, f"{net_id}.pth")
+    save_model = kwargs.get("save_model", saveat[:-4] + "final.pth")
+    net_res = None
+    for b_size in batch_size if isinstance(batch_size, list) else [batch_size]:
+        _say(f"<< {net_id} progress update >> B. Size: {b_size}; time: {dttm.datetime.now().strftime('%H:%M:%S')}\n",
+             use_file)
+        num_workers = kwargs["def_nworkers"](b_size) if "def_nworkers" in kwargs else 0
+        p_factor = kwargs["def_prefetch"](b_size) if "def_prefetch" in kwargs and num_workers else None
+        scheduler, ret_lr = None, False
+        if use_scheduler:                                        # poly schedule, deepv3_funcs.py:148-153
+            if min_lr:
+                w = (min_lr / lr) ** (1 / .9)
+                N_0 = num_epochs * w / (1 - w)
+                scheduler = optim.lr_scheduler.LambdaLR(
+                    optimizer, lr_lambda=lambda k: (1 - k / (num_epochs + N_0)) ** .9)
+            else:
+                scheduler = optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda k: (1 - k / num_epochs) ** .9)
+            ret_lr = True
+        train_loader = utils.data.DataLoader(train_set, batch_size=b_size, shuffle=True, num_workers=num_workers,
+                                             drop_last=True, prefetch_factor=p_factor, pin_memory=True)
+        aux = train(net, train_loader, loss, val_iter=val_loader, num_epochs=num_epochs, updater=optimizer,
+                    patience=patience, saveat=saveat, start_from=start_from or None, device=device,
+                    use_file=use_file, verbose=True, metrics=train_metrics, name=net_id, scheduler=scheduler,
+                    min_lr=min_lr, ret_lr=ret_lr, minimize=minimize, n_branches=n_branches,
+                    nout_channels=kwargs["nout_channels"])
+        net_res = {k: v + aux[k] for k, v in net_res.items()} if net_res else aux      # B-10 fixed
+    DataFrame.from_dict({k: v for k, v in net_res.items()}).to_csv(os.path.join(res_dir, f"{net_id}_tr.csv"),
+                                                                   index=False)
+    save_dict = torch.load(saveat, weights_only=True)
+    net.load_state_dict(save_dict["model_state_dict"])
+    torch.save(net.state_dict(), save_model)       # state_dict, not a pickled module (safe to reload)
+    _say(f"--> Finished training {net_id} (time: {dttm.datetime.now().strftime('%m/%d %H:%M:%S')})\n", use_file)
+    return save_model
+
+
+def eval_deepv3(kwargs):
+    res_dir, device = kwargs["res_dir"], kwargs["device"]
+    use_file, name = kwargs.get("use_file"), kwargs["name"]
+    saveat = os.path.join(res_dir, name)
+    kwargs["mod_dir"] = saveat
+    os.makedirs(saveat, exist_ok=True)
+    n_branches = kwargs["n_branches"]
+    btype = kwargs.get("type", "resnet101")                      # B-1: the reference ignores -t
+    C = kwargs["nout_channels"]
+    fine_tune = kwargs.get("fine_tune")
+    net = dv3.branchyDeepv3(fine_tune or None, f"deeplabv3_{btype}", n_branches, kwargs["input_dim"],
+                            count_branches=kwargs["count_branches"], skip=kwargs["skip"],
+                            branch_params=kwargs.get("branch_params"), num_classes=C,
+                            compute_dtype=kwargs.get("compute_dtype", torch.float32))
+    net.to(device)
+    if n_branches and n_branches != net.n_branches:
+        n_branches = net.n_branches
+        kwargs["loss"].update_n(n_branches)
+        kwargs["n_branches"] = n_branches
+        _say(f"<< {name} progress update >> Number of branches is different then antecipated: {n_branches} "
+             f"branches\n", use_file)
+    final_model = os.path.join(saveat, name + ".pth")
+    if kwargs.get("num_epochs", 0):
+        val_loader = utils.data.DataLoader(kwargs["val_set"], batch_size=5, shuffle=False, num_workers=0,
+                                           drop_last=False)
+        kwargs |= {"val_loader": val_loader, "save_model": final_model}
+        final_model = train_deepv3(net, kwargs["num_epochs"], kwargs)
+        net.load_state_dict(torch.load(final_model, weights_only=True))
+    else:
+        torch.save(net.state_dict(), final_model)
+    net.to(device)
+    net.eval()
+    test_loader = utils.data.DataLoader(kwargs["test_set"], batch_size=5, shuffle=False, num_workers=0,
+                                        drop_last=False)
+    aux_res = mIoU_evaluator(net, n_branches + 1, C, test_loader, device)
+    res = defaultdict(list)
+    res["net_id"].append(name)
+    for key, val in aux_res.items():
+        res[key].append(val)
+    mIoU_res = f"./mIoU_{n_branches}_branches_results.csv"
+    DataFrame.from_dict(res).set_index("net_id").to_csv(mIoU_res, mode="a", header=not os.path.exists(mIoU_res))
+    return final_model

@@ -460,3 +460,22 @@ def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1):
     check(lib().eeseg_entropy_gate(_p(lr), ldc, N, C_, h, w, H, W, pool, pool_size, float(tau), _p(ent), _p(flag),
                                    _p(ws), ws.numel(), _stream()), "eeseg_entropy_gate")
     return ent, flag
+
+
+def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None):
+    """scores [N,C,H,W] fp32 contiguous, target [N,H,W] int64.  Returns (loss[1], dscores|None)."""
+    _need_cuda(scores, target)
+    N, C_, H, W = scores.shape
+    assert scores.is_contiguous() and scores.dtype == torch.float32
+    assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
+    P = N * H * W
+    wsb = lib().eeseg_lovasz_workspace(P, C_)
+    if wsb < 0:
+        raise _lib.EesegError("lovasz: N*H*W*C must be < 2^31")
+    ws = workspace(wsb, scores.device)
+    loss = torch.empty(1, dtype=torch.float32, device=scores.device)
+    ds = torch.empty_like(scores) if want_grad else None
+    check(lib().eeseg_lovasz(_p(scores), _p(target), N, C_, H * W, int(-1 if ignore_index is None else ignore_index),
+                             _p(loss), _p(ds), float(gscale), _p(gscale_dev), _p(ws), ws.numel(), _stream()),
+          "eeseg_lovasz")
+    return loss, ds

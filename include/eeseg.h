@@ -200,6 +200,19 @@ int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int
                        int pool_size, float tau, float* entropy_out, int32_t* exit_flag, void* workspace,
                        int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------ lovasz ------
+ * Multi-class Lovasz on RAW scores for one exit (branchy_seg_losses.py:154 ->
+ * lovaszsoftmax.py:172-200), per_image=False, classes='present'.
+ * scores: [N,C,HW] fp32 (full resolution, NCHW), target [N,HW] int64 (labels outside
+ * [0,C) or == ignore_index are void).  loss_out[0] = mean over classes present;
+ * dscores (optional, [N,C,HW]) = gscale*gscale_dev[0] * d(loss)/d(scores).
+ * Ties between equal errors are ordered by pixel index (torch.sort leaves them
+ * unspecified); the loss value is tie-invariant. */
+int64_t eeseg_lovasz_workspace(int64_t P, int C);
+int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
+                 float* loss_out, float* dscores, float gscale, const float* gscale_dev, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------- SGD ------
  * torch.optim.SGD(momentum, weight_decay) step, multi-tensor
  * (deepv3_funcs.py:99; train_funcs.py:27).  ptrs: device array of

@@ -349,3 +349,43 @@ def test_sgd_step_matches_torch():
         torch.cuda.synchronize()
         for p, r in zip(dev, ref):
             close(p, r, 1e-6, f"sgd step {step}")
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_lovasz_matches_reference_golden(path):
+    """Raw-logit multi-exit Lovasz (branchy_seg_losses.py:133-159) through the HIP sort+scan
+    kernels vs the values and gradients the reference itself produced."""
+    from ee_semantic_segmentation_amd.branchy_seg_losses import LovaszSoftmax
+    g = np.load(path)
+    y, t, void = torch.from_numpy(g["y"]), torch.from_numpy(g["t"]), int(g["void"])
+    E = y.shape[0]
+    for prev in (False, True):
+        yd = y.clone().to(DEV).requires_grad_(True)
+        crit = LovaszSoftmax(classes="present", ignore=void, n_branches=E - 1, prev_out=prev)
+        loss = crit(yd, t.to(DEV))
+        loss.mean().backward()
+        want = float(g[f"lovasz_prev{int(prev)}"])
+        assert abs(loss.item() - want) < 3e-6 * max(1.0, abs(want)), (loss.item(), want)
+        np.testing.assert_allclose(yd.grad.cpu().numpy(), g[f"lovasz_prev{int(prev)}_grad"], rtol=2e-4, atol=2e-7)
+
+
+def test_lovasz_edge_cases():
+    from ee_semantic_segmentation_amd.branchy_seg_losses import lovasz_softmax
+    from oracle import losses_ref
+    gen = torch.Generator().manual_seed(5)
+    # only void pixels -> 0 ; one pixel ; a class that is absent ; sizes that are not multiples of the scan block
+    y = torch.randn(1, 4, 3, 5, generator=gen)
+    t = torch.full((1, 3, 5), 4)
+    assert lovasz_softmax(y.to(DEV), t.to(DEV), ignore=4).item() == 0.0
+    for shape, C in [((1, 3, 1, 1), 3), ((2, 6, 47, 53), 6), ((1, 5, 70, 64), 5)]:
+        y = torch.randn(*shape, generator=gen)
+        t = torch.randint(0, C - 1, (shape[0], shape[2], shape[3]), generator=gen)      # class C-1 never present
+        t[0, 0, 0] = C                                                                  # one void pixel
+        yr = y.clone().requires_grad_(True)
+        want = losses_ref.lovasz_softmax(yr, t, ignore=C)
+        want.backward()
+        yd = y.clone().to(DEV).requires_grad_(True)
+        got = lovasz_softmax(yd, t.to(DEV), ignore=C)
+        got.backward()
+        assert abs(got.item() - want.item()) < 3e-6 * max(1.0, abs(want.item())), shape
+        close(yd.grad, yr.grad, 2e-4, f"lovasz grad {shape}")
