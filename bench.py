@@ -98,8 +98,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
@@ -198,7 +199,7 @@ def main():
                 "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
                                        f"per-exit CE (sum), SGD momentum 0.9 wd 5e-4",
                            "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
-                           "hip_graph": not args.no_graph,
+                           "hip_graph": bool(runner.graph is not None),
                            "flop_per_image": flop_img, "loss_last_step": loss_val},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
@@ -206,7 +207,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.arch, args.branches, C, img, 2, 1234)
             log("cpu baseline done")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

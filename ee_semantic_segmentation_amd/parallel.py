@@ -11,6 +11,8 @@ the optimizer step.  xGMI is point-to-point, so buckets are large (default 64 Mi
 BatchNorm statistics (engine.Config.sync_bn) and the CE valid-pixel count are
 all-reduced inside the respective layers.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -115,6 +117,9 @@ class ArenaReducer:
         if self.arena is None:
             raise RuntimeError("call net.enable_grad_arena() first")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # EESEG_FORCE_ALLREDUCE=1: issue the collectives even in a 1-rank group (lets a single
+        # GPU exercise the RCCL-inside-HIP-graph path the multi-GPU bench relies on)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("EESEG_FORCE_ALLREDUCE") == "1")
         self.buckets = []            # (first unit, last unit, start, end)
         u0, start = 0, 0
         for u, (a, b) in enumerate(self.arena.unit_ranges):
@@ -124,7 +129,7 @@ class ArenaReducer:
         self._done = set()
         self._next = 0
         self._works = []
-        if self.world > 1:
+        if self.active:
             self.cfg.on_unit_done = self._unit_done
 
     def _unit_done(self, uid):
@@ -143,7 +148,7 @@ class ArenaReducer:
         self._works.append((dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg, op))
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets):       # units that produced no gradient this step
             _, _, a, b = self.buckets[self._next]
@@ -196,9 +201,22 @@ class GraphedTrainStep:
             self.X, self.y = X.clone(), y.clone()
             before = [b._pending_batches for b in self._bns]
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss = self._eager(self.X, self.y)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self.loss = self._eager(self.X, self.y)
+            except Exception as exc:                # e.g. a collective that cannot be captured
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training step failed ({exc!r}); running eagerly")
+                torch.cuda.synchronize()
+                if self.reducer is not None and hasattr(self.reducer, "_works"):
+                    self.reducer._works, self.reducer._next = [], 0
+                    getattr(self.reducer, "_done", set()).clear()
+                for b, n in zip(self._bns, before):
+                    b._pending_batches = n
+                self.use_graph = False
+                return self._eager(X, y)
+            self.graph = graph
             self._active = [b for b, n in zip(self._bns, before) if b._pending_batches != n]
             for b, n in zip(self._bns, before):
                 b._pending_batches = n              # capture itself does not run the kernels
