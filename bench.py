@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=2)
     args = ap.parse_args()
 
+    # RCCL / HIP print banners on stdout: keep fd 1 for the single JSON line only
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,15 +182,23 @@ def main():
         roof = None
         if prof:
             fam = {}
-            for name, flops, e0, e1 in prof:
-                f = fam.setdefault(name, [0.0, 0.0, 0])
+            for name, flops, e0, e1, nbytes in prof:
+                f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
                 f[0] += flops
                 f[1] += e0.elapsed_time(e1) * 1e-3
                 f[2] += 1
-            name, (fl, sec, cnt) = max(fam.items(), key=lambda kv: kv[1][1])
+                f[3] += nbytes
+            name, (fl, sec, cnt, nb) = max(fam.items(), key=lambda kv: kv[1][1])
+            traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (profiles/, offline)
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath))
+                if t.get("workload_key") == f"{args.arch}-{E}-{img}-{B}-{args.dtype}":
+                    traffic = t.get("hbm_bytes_per_launch", {}).get(name)
             roof = {"kernel": name, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS
                     if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": fl / sec / 1e12 /
-                    (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": None,
+                    (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": nb / cnt, "flops_per_launch": fl / cnt,
                     "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
                     "measured": f"HIP events around every launch, {prof_steps} eager steps after the timed region",
                     "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / prof_steps * 1e3,
@@ -206,7 +218,7 @@ def main():
             log("cpu baseline (oracle, torch CPU fp32) ...")
             line["cpu_baseline"] = cpu_baseline(args.arch, args.branches, C, img, 2, 1234)
             log("cpu baseline done")
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

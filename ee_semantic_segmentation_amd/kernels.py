@@ -80,12 +80,12 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev, family, flops):
+def _prof_end(ev, family, flops, nbytes=0.0):
     if ev is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
-    PROFILE.append((family, flops, ev, end))
+    PROFILE.append((family, flops, ev, end, nbytes))
 
 
 def workspace(nbytes, device):
@@ -118,7 +118,9 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     if ev is not None:
         px = N * (Hin * Win if sdiv > 1 else Hout * Wout)      # algorithmic MACs (padding taps included)
         fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
-        _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S)
+        es = 2 if a.dtype == BF16 else 4       # algorithmic bytes: every operand once
+        _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S,
+                  float(es) * (N * Hin * Win * Cin + Cout * R * S * Cin + N * Hout * Wout * Cout))
 
 
 def conv_fwd(x, w, stride=1, pad=0, dil=1, *, want_stats=False, scale=None, shift=None, residual=None,
@@ -184,8 +186,10 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     ev = _prof_begin()
     check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
     if ev is not None:
+        es = 2 if a.dtype == BF16 else 4
         _prof_end(ev, f"conv_wgrad_kernel<{'bf16' if a.dtype == BF16 else 'f32'}>",
-                  2.0 * N * Ho * Wo * Cout * Cin * R * S)
+                  2.0 * N * Ho * Wo * Cout * Cin * R * S,
+                  float(es) * (N * H * W * Cin + N * Ho * Wo * Cout) + 4.0 * Cout * R * S * Cin)
     return out
 
 

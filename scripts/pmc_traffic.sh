@@ -1,0 +1,35 @@
+#!/bin/bash
+# HBM traffic of every kernel of one eager bench step (run on the GPU box from the repo root).
+# Separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC slots), kernel-trace only.
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events > $out/$c.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python3 - <<PY
+import csv, glob, json, collections, re
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$out/%s/**/*counter_collection.csv" % c, recursive=True)
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == c:
+            a = agg[r["Kernel_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    res[c] = agg
+def short(n):
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I(DF16b|f)(?:Li(\d+))?", n)
+    if m:
+        return f"{m.group(1)}<{'bf16' if m.group(2) == 'DF16b' else 'f32'}{',' + m.group(3) if m.group(3) else ''}>"
+    return re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", ""))[:60]
+out = {}
+for k in res["FETCH_SIZE"]:
+    fs, n = res["FETCH_SIZE"][k]; ws, n2 = res["WRITE_SIZE"].get(k, [0.0, 1])
+    # units: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half of wide coalesced reads -> x2
+    out[short(k)] = {"launches": n, "fetch_bytes_per_launch": 2 * fs * 1024 / n, "write_bytes_per_launch": ws * 1024 / max(n2, 1),
+                     "hbm_bytes_per_launch": (2 * fs + ws * n / max(n2, 1)) * 1024 / n}
+json.dump(out, open("$out/traffic_raw.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
+    print(f"{k:40s} n={v['launches']:4d} fetch/launch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write/launch {v['write_bytes_per_launch']/1e6:9.2f} MB")
+PY
