@@ -60,7 +60,12 @@ __device__ __forceinline__ bool map_coord(int base, int t, int tstep, int sdiv, 
 constexpr int BM = 128;     // pixels per tile
 constexpr int ROWB = 128;   // bytes of K per LDS row
 
-template <typename T, int BN, int PIPE>
+// LINEAR (sdiv == 1): K order = channel chunk OUTER, filter tap INNER, so at any moment every
+// resident block streams the same 128-byte channel slice of the activation for all taps (L2-hot:
+// ~0.5 MB per image) instead of re-streaming the whole tensor once per tap; gather offsets are
+// base[row] + delta[tap] with a per-row valid-tap bit mask.  !LINEAR (strided data-gradient, where
+// the source coordinate is not linear in the tap): tap outer, offsets recomputed per tap.
+template <typename T, int BN, int PIPE, bool LINEAR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     constexpr int EPK = ROWB / (int)sizeof(T);        // K elements per step
     constexpr int WAVES_C = BN / 64;                  // waves along cout
@@ -108,19 +113,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     // ---- which taps can any pixel of this tile see? ---------------------------
     if (tid == 0) *sMask = 0u;
     __syncthreads();
+    unsigned vmask[4] = {0u, 0u, 0u, 0u};        // per gathered row: taps that land inside the image
     {
         unsigned mine = 0u;
         for (int t = 0; t < taps; ++t) {
             const int r = t / p.S, s = t - r * p.S;
-            bool any = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int hi, wi;
-                any |= map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) &&
-                       map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi);
+                if (map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) && map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi))
+                    vmask[j] |= 1u << t;
             }
-            if (any) mine |= 1u << t;
         }
+        mine = vmask[0] | vmask[1] | vmask[2] | vmask[3];
         // OR-reduce inside the wave, then one LDS atomic per wave
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
@@ -147,10 +152,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     // tap goes through the buffer instruction's scalar offset (no per-K-step VALU address math).
     // An out-of-image row keeps voffset = EESEG_OOB: voffset + soffset stays out of range -> zeros.
     uint32_t voffA[4], voffW[WCH];
+    int baseA[4];                 // LINEAR: byte offset of the tap-(0,0) source pixel (may be negative)
     unsigned rest = tapmask;
-    int ci = kc_steps - 1;      // forces a tap advance on the first next_tile()
+    int ci = LINEAR ? 0 : kc_steps - 1;      // !LINEAR: forces a tap advance on the first next_tile()
+    int cur_tap = 0, soffA = 0, soffW = 0;
+    bool live = nk > 0;
 
-    auto set_tap = [&](int tap) {
+    auto set_tap = [&](int tap) {            // !LINEAR only
         const int r = tap / p.S, s = tap - r * p.S;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -165,27 +173,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             voffW[j] = (co < p.Cout) ? (uint32_t)(((co * taps + tap) * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
         }
     };
-    auto next_tile = [&]() {   // block-uniform iterator over (valid tap, channel step)
-        if (++ci >= kc_steps) {
-            ci = 0;
-            if (rest) {
-                const int tap = __ffs(rest) - 1;
-                rest &= rest - 1;
-                set_tap(tap);
-            } else {           // past the last tile: every load becomes an out-of-range (zero, no traffic) load
+    if constexpr (LINEAR) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) voffA[j] = EESEG_OOB;
+        for (int j = 0; j < 4; ++j) baseA[j] = ((nb[j] + hb[j] * p.Win + wb[j]) * p.Cin) * (int)sizeof(T) + lchunk * 16;
 #pragma unroll
-                for (int j = 0; j < WCH; ++j) voffW[j] = EESEG_OOB;
+        for (int j = 0; j < WCH; ++j) {
+            const int co = n0 + lrow + 32 * j;
+            voffW[j] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
+        }
+    }
+    auto next_tile = [&]() {   // block-uniform iterator over the K tiles
+        if constexpr (LINEAR) {
+            if (!rest) { rest = tapmask; ++ci; }
+            live = live && ci < kc_steps;
+            cur_tap = __ffs(rest) - 1;
+            rest &= rest - 1;
+            const int r = cur_tap / p.S, s = cur_tap - r * p.S;
+            const int dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * (int)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                voffA[j] = (live && ((vmask[j] >> cur_tap) & 1u)) ? (uint32_t)(baseA[j] + dtap) : EESEG_OOB;
+            soffA = ci * ROWB;
+            soffW = live ? (cur_tap * p.Cin) * (int)sizeof(T) + ci * ROWB : 0x7FFFFF00;
+        } else {
+            if (++ci >= kc_steps) {
+                ci = 0;
+                if (rest) {
+                    const int tap = __ffs(rest) - 1;
+                    rest &= rest - 1;
+                    set_tap(tap);
+                } else {       // past the last tile: every load becomes an out-of-range (zero, no traffic) load
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) voffA[j] = EESEG_OOB;
+#pragma unroll
+                    for (int j = 0; j < WCH; ++j) voffW[j] = EESEG_OOB;
+                }
             }
+            soffA = soffW = ci * ROWB;
         }
     };
     auto load_tile = [&](i32x4 (&ra)[4], i32x4 (&rwv)[WCH]) {
-        const int soff = ci * ROWB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voffA[j], soff, 0);
+        for (int j = 0; j < 4; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voffA[j], soffA, 0);
 #pragma unroll
-        for (int j = 0; j < WCH; ++j) rwv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)voffW[j], soff, 0);
+        for (int j = 0; j < WCH; ++j) rwv[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)voffW[j], soffW, 0);
     };
     auto store_tile = [&](int buf, const i32x4 (&ra)[4], const i32x4 (&rwv)[WCH]) {
 #pragma unroll
@@ -378,15 +409,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+int g_conv_linear = 0;   // eeseg_set_option(EESEG_OPT_CONV_TAP_INNER, 0|1)
 int g_conv_pipe = 2;     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
 
 template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
-    if (g_conv_pipe == 2)
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2>), dim3(grid), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1>), dim3(grid), dim3(256), 0, st, p);
+    const bool lin = (p.sdiv == 1) && g_conv_linear;
+    if (g_conv_pipe == 2 && lin) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
+    } else {   // the tap-outer form keeps the 1-deep pipeline (the 2-deep one spills there)
+        if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, true>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, false>), dim3(grid), dim3(256), 0, st, p);
+    }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -396,6 +431,10 @@ int launch(const ConvP& p, hipStream_t st) {
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value == 1 || value == 2)) {
         g_conv_pipe = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_TAP_INNER && (value == 0 || value == 1)) {
+        g_conv_linear = value;
         return EESEG_OK;
     }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);

@@ -181,30 +181,36 @@ __global__ __launch_bounds__(256) void colsum_stage1(const T* x, int ldx, long l
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, const T* y, int ldy, const T* x, int ldx,
-                                                     const float* mean_invstd, long long rows,
-                                                     long long rows_per_block, int C, int relu, int TX, float* partials) {
+                                                     const float* mean_invstd, const float* scale_shift,
+                                                     long long rows, long long rows_per_block, int C, int relu, int TX,
+                                                     float* partials) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long rb = (long long)blockIdx.y * rows_per_block;
     const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
     const int c0t = (blockIdx.x * TX + (threadIdx.x % TX)) * EPC;
-    float mu[EPC], is[EPC];
+    // relu: 0 none, 1 mask from y > 0, 2 mask recomputed as x*scale+shift > 0 (no y read)
+    float mu[EPC], is[EPC], msc[EPC], msh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const bool ok = c0t + e < C;
         mu[e] = ok ? mean_invstd[c0t + e] : 0.f;
         is[e] = ok ? mean_invstd[C + c0t + e] : 0.f;
+        msc[e] = (ok && relu == 2) ? scale_shift[c0t + e] : 0.f;
+        msh[e] = (ok && relu == 2) ? scale_shift[C + c0t + e] : 0.f;
     }
     colreduce_body<T, 2>(
         [&](long long r, int c0, float (*acc)[EPC]) {
             Vec<T> g = ld16(dy + r * lddy + c0);
             Vec<T> xv = ld16(x + r * ldx + c0);
             Vec<T> yv;
-            if (relu) yv = ld16(y + r * ldy + c0);
+            if (relu == 1) yv = ld16(y + r * ldy + c0);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 float gf = to_f32(g.e[e]);
-                if (relu && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
-                const float xh = (to_f32(xv.e[e]) - mu[e]) * is[e];
+                const float xf = to_f32(xv.e[e]);
+                if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+                if (relu == 2 && !(to_f32(from_f32<T>(xf * msc[e] + msh[e])) > 0.f)) gf = 0.f;
+                const float xh = (xf - mu[e]) * is[e];
                 acc[0][e] += gf;
                 acc[1][e] += gf * xh;
             }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_count, T* dx,
                                                            int lddx, T* dres, int lddres, long long rows, int C,
-                                                           int relu) {
+                                                           int relu, const float* __restrict__ scale_shift) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -339,10 +345,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     const int c0 = (int)(gid % cpr) * EPC;
     const long long rstep = T_ / cpr;
     // dx = ka*g + kb*(x - mean) + kc   (MODE 0: ka = gamma*invstd, kb = -ka*invstd*s1/n, kc = -ka*s0/n)
-    float ka[EPC], kb[EPC], kc[EPC], km[EPC];
+    float ka[EPC], kb[EPC], kc[EPC], km[EPC], msc[EPC], msh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const int c = c0 + e;
+        msc[e] = (relu == 2) ? scale_shift[c] : 0.f;
+        msh[e] = (relu == 2) ? scale_shift[C + c] : 0.f;
         if (MODE == 0) {
             const float mu = mean_invstd[c], is = mean_invstd[C + c];
             const float ga = gamma ? gamma[c] : 1.f;
@@ -357,13 +365,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     for (long long r = gid / cpr; r < rows; r += rstep) {
         Vec<T> g = ld16(dy + r * lddy + c0);
         Vec<T> yv, xv;
-        if (relu) yv = ld16(y + r * ldy + c0);
+        if (relu == 1) yv = ld16(y + r * ldy + c0);
         if (MODE == 0) xv = ld16(x + r * ldx + c0);
         Vec<T> od, og;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float gf = to_f32(g.e[e]);
-            if (relu && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+            if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+            if (MODE == 0 && relu == 2 && !(to_f32(from_f32<T>(to_f32(xv.e[e]) * msc[e] + msh[e])) > 0.f)) gf = 0.f;
             og.e[e] = from_f32<T>(gf);
             float d = ka[e] * gf;
             if (MODE == 0) d += kb[e] * (to_f32(xv.e[e]) - km[e]) + kc[e];
@@ -494,6 +503,48 @@ __global__ __launch_bounds__(256) void sum_hw_kernel(const T* x, int ldx, T* y, 
         }
         st16(y + (long long)n * C + c0, o);
     }
+}
+
+// two-stage variant for large HW: grid = (col blocks, N, splits) -> fp32 partials [split][N][C]
+template <typename T>
+__global__ __launch_bounds__(256) void sum_hw_part_kernel(const T* x, int ldx, float* part, int N, int HW, int C,
+                                                          int rows_per_split) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    __shared__ float sred[8][32][EPC + 1];
+    const int tx = threadIdx.x, ty = threadIdx.y, n = blockIdx.y, sp = blockIdx.z;
+    const int c0 = (blockIdx.x * 32 + tx) * EPC;
+    const int r0 = sp * rows_per_split, r1 = min(HW, r0 + rows_per_split);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        for (int r = r0 + ty; r < r1; r += 8) {
+            Vec<T> v = ld16(x + ((long long)n * HW + r) * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += to_f32(v.e[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) sred[ty][tx][e] = acc[e];
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += sred[q][tx][e];
+            part[((long long)sp * N + n) * C + c0 + e] = s;
+        }
+    }
+}
+
+template <typename T>
+__global__ void sum_hw_fin_kernel(const float* __restrict__ part, T* y, int NC, int splits, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[(long long)sp * NC + i];
+    y[i] = from_f32<T>(s * scale);
 }
 
 // y[n][hw][ldy slice] (+)= x[n][c] * scale
@@ -687,7 +738,7 @@ static int launch_reduce_partials(const float* partials, int tiles, int KC, floa
                                   hipStream_t st) {
     const int colblocks = (KC + 63) / 64;
     int segs = 1;
-    if (tiles >= 512 && scratch) {
+    if (tiles >= 2048 && scratch) {
         segs = tiles / 128;
         if (segs > 32) segs = 32;
     }
@@ -823,34 +874,35 @@ extern "C" int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* 
 }
 
 extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                                   const float* mean_invstd, int64_t rows, int C, int relu, float* sums, int dtype,
-                                   void* workspace, int64_t workspace_bytes, void* stream) {
-    EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && (!relu || y), EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
+                                   const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
+                                   float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+    EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && (relu != 1 || y) && (relu != 2 || scale_shift) &&
+                    relu >= 0 && relu <= 2, EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
     CHECK_ROWS("bn_bwd_reduce dy", dy, lddy, C, dtype);
     CHECK_ROWS("bn_bwd_reduce x", x, ldx, C, dtype);
-    if (relu) CHECK_ROWS("bn_bwd_reduce y", y, ldy, C, dtype);
+    if (relu == 1) CHECK_ROWS("bn_bwd_reduce y", y, ldy, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EESEG_BF16)
         return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
             hipLaunchKernelGGL((bn_bwd_stage1<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)y,
-                               ldy, (const bf16_t*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, TX, part);
+                               ldy, (const bf16_t*)x, ldx, mean_invstd, scale_shift, (long long)rows, rpb, C, relu, TX, part);
         }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
     return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
         hipLaunchKernelGGL((bn_bwd_stage1<float>), g, dim3(256), 0, st, (const float*)dy, lddy, (const float*)y, ldy,
-                           (const float*)x, ldx, mean_invstd, (long long)rows, rpb, C, relu, TX, part);
+                           (const float*)x, ldx, mean_invstd, scale_shift, (long long)rows, rpb, C, relu, TX, part);
     }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
 }
 
 extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                   const float* mean_invstd, const float* gamma, const float* sums, double count,
-                                  void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
-                                  void* stream) {
-    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && (!relu || y), EESEG_ERR_ARG,
-                "bn_bwd_apply: bad argument");
+                                  void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu,
+                                  const float* scale_shift, int dtype, void* stream) {
+    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && (relu != 1 || y) &&
+                    (relu != 2 || scale_shift) && relu >= 0 && relu <= 2, EESEG_ERR_ARG, "bn_bwd_apply: bad argument");
     CHECK_ROWS("bn_bwd_apply dy", dy, lddy, C, dtype);
     CHECK_ROWS("bn_bwd_apply x", x, ldx, C, dtype);
     CHECK_ROWS("bn_bwd_apply dx", dx, lddx, C, dtype);
-    if (relu) CHECK_ROWS("bn_bwd_apply y", y, ldy, C, dtype);
+    if (relu == 1) CHECK_ROWS("bn_bwd_apply y", y, ldy, C, dtype);
     if (dres) CHECK_ROWS("bn_bwd_apply dres", dres, lddres, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
@@ -859,11 +911,11 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
-                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu);
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
-                           (float*)dres, lddres, (long long)rows, C, relu);
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -882,11 +934,13 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
-                           (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu);
+                           (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
-                           (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu);
+                           (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -931,13 +985,33 @@ extern "C" int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, i
 }
 
 extern "C" int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype,
-                            void* stream) {
+                            void* workspace, int64_t workspace_bytes, void* stream) {
     EESEG_CHECK(x && y && N > 0 && HW > 0, EESEG_ERR_ARG, "sum_hw: bad argument");
     CHECK_ROWS("sum_hw x", x, ldx, C, dtype);
     CHECK_ROWS("sum_hw y", y, C, C, dtype);
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
-    dim3 g((C / epc + 31) / 32, N);
+    const int colblocks = (C / epc + 31) / 32;
+    int splits = HW / 256;                      // >= 256 rows per split
+    if (splits > 16) splits = 16;
+    if (splits >= 2 && workspace && workspace_bytes >= (int64_t)splits * N * C * (int64_t)sizeof(float)) {
+        const int rps = (HW + splits - 1) / splits;
+        dim3 g(colblocks, N, splits);
+        if (dtype == EESEG_BF16) {
+            hipLaunchKernelGGL((sum_hw_part_kernel<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (float*)workspace,
+                               N, HW, C, rps);
+            hipLaunchKernelGGL((sum_hw_fin_kernel<bf16_t>), dim3((N * C + 255) / 256), dim3(256), 0, st,
+                               (const float*)workspace, (bf16_t*)y, N * C, splits, scale);
+        } else {
+            hipLaunchKernelGGL((sum_hw_part_kernel<float>), g, dim3(32, 8), 0, st, (const float*)x, ldx, (float*)workspace, N,
+                               HW, C, rps);
+            hipLaunchKernelGGL((sum_hw_fin_kernel<float>), dim3((N * C + 255) / 256), dim3(256), 0, st,
+                               (const float*)workspace, (float*)y, N * C, splits, scale);
+        }
+        EESEG_LAUNCH_CHECK();
+        return EESEG_OK;
+    }
+    dim3 g(colblocks, N);
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((sum_hw_kernel<bf16_t>), g, dim3(32, 8), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, HW, C, scale);
     else

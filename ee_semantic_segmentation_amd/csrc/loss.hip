@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void upsample_nchw_bwd_kernel(const float* __r
 }
 
 // ------------------------------------------------------ cross entropy fwd ----
-// accum (double[2]): [0] += sum over valid pixels of (lse - z[target]); [1] += #valid
+// accum (double[2]): [0] += sum over valid pixels of (lse - z[target]); [1] += #valid.
+// One half wave per (n, y, x0): all full-res pixels of row y whose left source column is x0
+// share the same four low-res logit vectors, which are loaded once per span.
 __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __restrict__ lr, int ldc,
                                                               const int64_t* __restrict__ target, int N, int C, int h,
                                                               int w, int H, int W, long long ignore_index,
@@ -117,24 +119,43 @@ __global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(const float* __res
     const int lane32 = threadIdx.x & 31;
     const int half = threadIdx.x >> 5;                 // 8 half waves per block
     const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-    const long long total = (long long)N * H * W;
+    const long long total = (long long)N * H * w;
     float loss_acc = 0.f, cnt_acc = 0.f;
     const bool active = lane32 < C;
-    for (long long p = (long long)blockIdx.x * 8 + half; p < total; p += (long long)gridDim.x * 8) {
-        const int x = (int)(p % W);
-        const long long t = p / W;
+    for (long long it = (long long)blockIdx.x * 8 + half; it < total; it += (long long)gridDim.x * 8) {
+        const int x0 = (int)(it % w);
+        const long long t = it / w;
         const int y = (int)(t % H);
         const int n = (int)(t / H);
-        const long long tg = target[p];
-        if (tg == ignore_index || tg < 0 || tg >= C) continue;   // half-wave uniform
-        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
-        const float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
-        const float m = half_max(z);
-        const float e = active ? __expf(z - m) : 0.f;
-        const float s = half_sum(e);
-        const float zt = __shfl(z, (int)tg, 32);
-        loss_acc += (m + __logf(s)) - zt;
-        cnt_acc += 1.f;
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        const int x1 = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + x1) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + x1) * ldc];
+        }
+        const int64_t* trow = target + ((long long)n * H + y) * W;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;                               // uniform over the half wave
+            const long long tg = trow[x];
+            if (tg == ignore_index || tg < 0 || tg >= C) continue;   // uniform
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float ssum = half_sum(e);
+            const float zt = __shfl(z, (int)tg, 32);
+            loss_acc += (m + __logf(ssum)) - zt;
+            cnt_acc += 1.f;
+        }
     }
     // every lane of a half wave carries the same partial; reduce over the 8 halves
     if (lane32 == 0) { sl[half] = loss_acc; sc[half] = cnt_acc; }
@@ -178,13 +199,23 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __res
         xa = (x0 == 0) ? 0 : max(xa, 0);      // sources clamped at 0 all land in column 0
         xb = min(xb, W - 1);
         const Src sy = src_index(y, sh, h);
+        const int xn = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;     // the span's four source vectors, loaded once
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + xn) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + xn) * ldc];
+        }
         float a0 = 0.f, a1 = 0.f;
         for (int x = xa; x <= xb; ++x) {
             const Src sx = src_index(x, sw, w);
             if (sx.i0 != x0) continue;                               // uniform over the half wave
             const long long tg = target[((long long)n * H + y) * W + x];
             if (tg == ignore_index || tg < 0 || tg >= C) continue;   // uniform
-            const float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
             const float m = half_max(z);
             const float e = active ? __expf(z - m) : 0.f;
             const float s = half_sum(e);
@@ -377,7 +408,7 @@ extern "C" int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int6
                                      int H, int W, int64_t ignore_index, double* accum, void* stream) {
     CHECK_LR("upsample_ce_fwd");
     EESEG_CHECK(target && accum && ((uintptr_t)accum & 7) == 0, EESEG_ERR_ARG, "upsample_ce_fwd: bad target/accum");
-    hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(px_grid((long long)N * H * w)), dim3(256), 0, (hipStream_t)stream,
                        logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;

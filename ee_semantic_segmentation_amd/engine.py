@@ -195,26 +195,29 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
     mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
     bn._pending_batches += 1
     y = K.bn_apply(c, ss, residual=residual, relu=relu, out=out)
-    return y, (x, c, y, mi, count, relu)
+    # backward recomputes the ReLU mask from c*scale+shift when there is no residual input
+    # (saves streaming y again); with a residual the stored output is the mask source
+    return y, (x, c, y if residual is not None else None, mi, count, relu, ss)
 
 
 def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):
     """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
     parameter gradients are None in arena mode (written in place)."""
-    x, c, y, mi, count, relu = st
+    x, c, y, mi, count, relu, ss = st
     pair = cfg.gview(bn)
     if pair is not None and cfg.accumulate:
-        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu)
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
         pair.add_(sums)
     else:
-        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair)
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
     if cfg.world() > 1:
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
         sums = sums.clone() if pair is not None else sums
         _allreduce(cfg, sums)
-    dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres)
+    dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
+                              scale_shift=ss)
     gv = cfg.gview(conv.weight)
     if x_is_col:
         dw = K.conv_wgrad(x, dc, 1, 1)

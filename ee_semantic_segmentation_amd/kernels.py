@@ -304,19 +304,27 @@ def colsum(x, out=None):
     return out
 
 
-def bn_bwd_reduce(dy, y, x, mean_invstd, relu, out=None):
+def _relu_mode(relu, y, scale_shift):
+    """0 none / 1 mask from stored y / 2 mask recomputed from x*scale+shift (no y read)."""
+    if not relu:
+        return 0
+    return 2 if (y is None and scale_shift is not None) else 1
+
+
+def bn_bwd_reduce(dy, y, x, mean_invstd, relu, out=None, scale_shift=None):
     rows, Cc, lddy = rows_ld(dy)
     _, _, ldx = rows_ld(x)
     ldy = rows_ld(y)[2] if y is not None else 0
     sums = out if out is not None else torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     assert sums.is_contiguous() and sums.shape == (2, Cc) and sums.dtype == torch.float32
     ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
-    check(lib().eeseg_bn_bwd_reduce(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), rows, Cc, int(relu),
-                                    _p(sums), _dt(x), _p(ws), ws.numel(), _stream()), "eeseg_bn_bwd_reduce")
+    check(lib().eeseg_bn_bwd_reduce(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), _p(scale_shift), rows, Cc,
+                                    _relu_mode(relu, y, scale_shift), _p(sums), _dt(x), _p(ws), ws.numel(),
+                                    _stream()), "eeseg_bn_bwd_reduce")
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean_invstd, gamma, sums, count, relu, *, want_dres=False, dx=None):
+def bn_bwd_apply(dy, y, x, mean_invstd, gamma, sums, count, relu, *, want_dres=False, dx=None, scale_shift=None):
     rows, Cc, lddy = rows_ld(dy)
     _, _, ldx = rows_ld(x)
     ldy = rows_ld(y)[2] if y is not None else 0
@@ -326,8 +334,9 @@ def bn_bwd_apply(dy, y, x, mean_invstd, gamma, sums, count, relu, *, want_dres=F
     dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
     lddres = rows_ld(dres)[2] if dres is not None else 0
     check(lib().eeseg_bn_bwd_apply(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), _p(gamma), _p(sums),
-                                   float(count), _p(dx), lddx, _p(dres), lddres, rows, Cc, int(relu), _dt(x),
-                                   _stream()), "eeseg_bn_bwd_apply")
+                                   float(count), _p(dx), lddx, _p(dres), lddres, rows, Cc,
+                                   _relu_mode(relu, y, scale_shift), _p(scale_shift), _dt(x), _stream()),
+          "eeseg_bn_bwd_apply")
     return dx, dres
 
 
@@ -364,7 +373,9 @@ def sum_hw(x, scale=1.0):
     N = x.shape[0]
     rows, Cc, ldx = rows_ld(x)
     y = torch.empty((N, Cc), dtype=x.dtype, device=x.device)
-    check(lib().eeseg_sum_hw(_p(x), ldx, _p(y), N, rows // N, Cc, float(scale), _dt(x), _stream()), "eeseg_sum_hw")
+    ws = workspace(16 * N * Cc * 4, x.device)
+    check(lib().eeseg_sum_hw(_p(x), ldx, _p(y), N, rows // N, Cc, float(scale), _dt(x), _p(ws), ws.numel(), _stream()),
+          "eeseg_sum_hw")
     return y
 
 

@@ -37,7 +37,8 @@ const char* eeseg_last_error(void);
 int eeseg_version(void);
 /* tuning switches (process wide).  EESEG_OPT_CONV_PIPE: global-load prefetch depth
  * of the implicit-GEMM conv kernel, 1 or 2 (default) K-steps. */
-enum { EESEG_OPT_CONV_PIPE = 1 };
+enum { EESEG_OPT_CONV_PIPE = 1, EESEG_OPT_CONV_TAP_INNER = 2 /* K order: 0 = taps outer (default), 1 = taps inner (fewer L2 misses,
+                                  measured 3% slower end to end on MI355X: the Infinity Cache absorbs the re-reads) */ };
 int eeseg_set_option(int key, int value);
 
 /* ---------------------------------------------------------------- conv ----
@@ -122,16 +123,19 @@ int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void*
  * conv epilogue, e.g. the pooled ASPP branch): sums[2][C] */
 int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype, void* workspace,
                         int64_t workspace_bytes, void* stream);
-/* backward, step 1: g = dy * (y > 0 if relu); sums[0][c] = sum g, sums[1][c] = sum g*xhat */
+/* backward, step 1: g = dy * mask; sums[0][c] = sum g, sums[1][c] = sum g*xhat.
+ * relu: 0 no activation; 1 mask = (y > 0) read from the stored output; 2 mask recomputed as
+ * (x*scale+shift > 0) from scale_shift[2][C] - for layers without a residual input this saves the
+ * read of y (one of the 3-4 streamed tensors). */
 int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
-                        const float* mean_invstd, int64_t rows, int C, int relu, float* sums, int dtype,
-                        void* workspace, int64_t workspace_bytes, void* stream);
+                        const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
+                        float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* backward, step 2: dx = gamma*invstd*(g - sums0/count - xhat*sums1/count);
  * dres (optional) = g.  dgamma = sums1, dbeta = sums0 (taken by the host). */
 int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                        const float* mean_invstd, const float* gamma, const float* sums, double count,
-                       void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
-                       void* stream);
+                       void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu,
+                       const float* scale_shift, int dtype, void* stream);
 /* frozen-BN / plain backward of y = act(x*scale+shift): dx = g*scale, dres = g */
 int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int ldy, const float* scale,
                         void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
@@ -145,7 +149,8 @@ int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H
                            int dtype, void* stream);
 /* per-image column sum: y[n][c] = scale * sum_hw x[n][hw][c] (ASPPPooling's
  * AdaptiveAvgPool2d(1) with scale = 1/HW; also the backward of the broadcast) */
-int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype, void* stream);
+int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype, void* workspace,
+                 int64_t workspace_bytes /* >= 16*N*C*4 enables the split reduction */, void* stream);
 /* y[n][hw][c] (+)= scale * x[n][c] into a channel slice of row stride ldy
  * (ASPPPooling's bilinear upsample from 1x1 is a broadcast; with scale = 1/HW
  * and accumulate = 1 it is the backward of the average pool) */

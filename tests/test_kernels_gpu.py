@@ -167,6 +167,10 @@ def test_batchnorm_train_fwd_bwd(dtype, relu, use_res):
     close(nchw(dx), x.grad, 3e-4 if dtype == torch.float32 else 3e-2, "bn dx")
     if use_res:
         close(nchw(dres), res.grad, tol(dtype), "bn dres")
+    elif relu:      # mask recomputed from x*scale+shift instead of reading y: identical results
+        bs2 = K.bn_bwd_reduce(gyd, None, xd, mi, relu, scale_shift=ss)
+        dx2, _ = K.bn_bwd_apply(gyd, None, xd, mi, gamma.detach().to(DEV), bs2, cnt, relu, scale_shift=ss)
+        assert torch.equal(bs2, bs) and torch.equal(dx2, dx)
 
 
 def test_bn_eval_and_frozen_bwd():
