@@ -44,6 +44,7 @@ SIGNATURES = {
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),
     "eeseg_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_pack_weight_multi": (_i, [_vp, _i, _i, _vp]),
     "eeseg_pack_matrix": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "eeseg_im2col_nchw": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "eeseg_colreduce_workspace": (_i64, [_i64, _i]),

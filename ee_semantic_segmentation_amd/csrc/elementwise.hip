@@ -47,6 +47,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* wf, T* wb, 
     }
 }
 
+// one launch packs every conv weight of the network: desc[t] = {src, w_fwd, w_bwd, Cout, Cout_pad, Cin, taps, krsc}
+struct PackDesc { const float* src; void* wf; void* wb; int Cout, Cout_pad, Cin, taps, krsc, pad_; };
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackDesc* __restrict__ desc) {
+    const PackDesc d = desc[blockIdx.y];
+    T* wf = (T*)d.wf;
+    T* wb = (T*)d.wb;
+    const long long total = (long long)d.Cout_pad * d.taps * d.Cin;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+        const int ci = (int)(i % d.Cin);
+        const long long r = i / d.Cin;
+        const int tap = (int)(r % d.taps);
+        const int co = (int)(r / d.taps);
+        float v = 0.f;
+        if (co < d.Cout) v = d.krsc ? d.src[((long long)co * d.taps + tap) * d.Cin + ci]
+                                    : d.src[((long long)co * d.Cin + ci) * d.taps + tap];
+        if (wf) wf[i] = from_f32<T>(v);
+        if (wb) wb[((long long)ci * d.taps + tap) * d.Cout_pad + co] = from_f32<T>(v);
+    }
+}
+
 template <typename T>
 __global__ void pack_matrix_kernel(const float* __restrict__ src, int rows, int cols, int lds, T* dst, int rows_pad,
                                    int cols_pad) {
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, cons
                 float gf = to_f32(g.e[e]);
                 const float xf = to_f32(xv.e[e]);
                 if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
-                if (relu == 2 && !(to_f32(from_f32<T>(xf * msc[e] + msh[e])) > 0.f)) gf = 0.f;
+                if (relu == 2 && !(xf * msc[e] + msh[e] > 0.f)) gf = 0.f;   // sign survives the bf16 rounding
                 const float xh = (xf - mu[e]) * is[e];
                 acc[0][e] += gf;
                 acc[1][e] += gf * xh;
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
         for (int e = 0; e < EPC; ++e) {
             float gf = to_f32(g.e[e]);
             if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
-            if (MODE == 0 && relu == 2 && !(to_f32(from_f32<T>(to_f32(xv.e[e]) * msc[e] + msh[e])) > 0.f)) gf = 0.f;
+            if (MODE == 0 && relu == 2 && !(to_f32(xv.e[e]) * msc[e] + msh[e] > 0.f)) gf = 0.f;
             og.e[e] = from_f32<T>(gf);
             float d = ka[e] * gf;
             if (MODE == 0) d += kb[e] * (to_f32(xv.e[e]) - km[e]) + kc[e];
@@ -673,6 +694,21 @@ extern "C" int eeseg_pack_weight(const float* src, void* w_fwd, void* w_bwd, int
                            (float*)w_bwd, Cout, Cout_pad, Cin, R * S, src_krsc);
     else
         EESEG_CHECK(false, EESEG_ERR_ARG, "pack_weight: bad dtype");
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_pack_weight_multi(const void* desc_table, int n, int dtype, void* stream) {
+    EESEG_CHECK(desc_table && n > 0 && n <= 65535, EESEG_ERR_ARG, "pack_weight_multi: bad argument");
+    static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI (48 bytes)");
+    if (dtype == EESEG_BF16)
+        hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(32, n), dim3(256), 0, (hipStream_t)stream,
+                           (const PackDesc*)desc_table);
+    else if (dtype == EESEG_F32)
+        hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(32, n), dim3(256), 0, (hipStream_t)stream,
+                           (const PackDesc*)desc_table);
+    else
+        EESEG_CHECK(false, EESEG_ERR_ARG, "pack_weight_multi: bad dtype");
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -110,6 +110,7 @@ class GradArena:
                 off += n_pad
             self.unit_ranges.append((start, off))
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.prezeroed = False         # True: the step zeroes `flat` once, weight gradients accumulate into it
         self.kernel_view = {}          # param (or bn module) -> tensor the kernels write
         for obj, what, o, n in plan:
             seg = self.flat[o:o + n]
@@ -152,6 +153,46 @@ class GradArena:
         e += [(aspp.project[0].weight, "w"), (aspp.project[1], "bn"), (h[1].weight, "w"), (h[2], "bn"),
               (h[4].weight, "cls_w"), (h[4].bias, "cls_b")]
         return e
+
+
+def pack_all(net, dtype):
+    """Pack every conv weight of `net` for the compute dtype in ONE launch (persistent packed
+    buffers, static device descriptor table) and mark the per-module caches current."""
+    import numpy as np
+    cfg = net.cfg
+    convs = []
+    for mod in net.modules():
+        if type(mod).__name__ == "Conv2d" and mod.weight.shape[1] != 3:        # the stem goes through packed_stem
+            is_cls = mod.bias is not None
+            convs.append((mod, torch.float32 if is_cls else dtype, CPAD if is_cls else None))
+    groups = {}
+    for mod, dt, cp in convs:
+        groups.setdefault(dt, []).append((mod, cp))
+    st = cfg.__dict__.setdefault("_pack_tables", {})
+    for dt, items in groups.items():
+        key = (dt, tuple(m.weight.data_ptr() for m, _ in items))
+        tab = st.get(dt)
+        if tab is None or tab[0] != key:
+            rec = np.zeros((len(items), 6), dtype=np.int64)
+            bufs = []
+            for i, (m, cp) in enumerate(items):
+                w = m.weight
+                co, ci, r, s_ = w.shape
+                cpad = cp or co
+                krsc = 1 if (w.is_contiguous(memory_format=torch.channels_last) or (r == 1 and s_ == 1)) else 0
+                wf = torch.empty((cpad, r, s_, ci), dtype=dt, device=w.device)
+                wb = torch.empty((ci, r, s_, cpad), dtype=dt, device=w.device)
+                bufs.append((wf, wb, cp))
+                rec[i, 0], rec[i, 1], rec[i, 2] = w.data_ptr(), wf.data_ptr(), wb.data_ptr()
+                rec[i, 3] = co | (cpad << 32)
+                rec[i, 4] = ci | ((r * s_) << 32)
+                rec[i, 5] = krsc
+            tab = (key, torch.from_numpy(rec).to(items[0][0].weight.device), bufs)
+            st[dt] = tab
+        K.pack_weight_multi(tab[1], len(items), dt)
+        for (m, cp), (wf, wb, _) in zip(items, tab[2]):
+            w = m.weight
+            m.__dict__["_eeseg_pack"] = ((w._version, _WEIGHTS_EPOCH[0], dt, w.data_ptr(), cp), wf, wb)
 
 
 def packed(conv, dtype, cout_pad=None):
@@ -234,7 +275,7 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     s, p, d = _geom(conv)
     R, S = conv.weight.shape[2], conv.weight.shape[3]
     if gv is not None:
-        K.conv_wgrad(x, dc, R, S, s, p, d, out=gv, accumulate=cfg.accumulate)
+        K.conv_wgrad(x, dc, R, S, s, p, d, out=gv, accumulate=cfg.accumulate or cfg.arena.prezeroed)
         dwp = None
     else:
         dwp = K.conv_wgrad(x, dc, R, S, s, p, d).permute(0, 3, 1, 2)
@@ -411,7 +452,7 @@ def head_bwd(cfg, state, dlogits, head):
             gvb.add_(K.colsum(dlogits))
         else:
             K.colsum(dlogits, out=gvb)
-        K.conv_wgrad(q32, dlogits, 1, 1, out=gvw, accumulate=cfg.accumulate)
+        K.conv_wgrad(q32, dlogits, 1, 1, out=gvw, accumulate=cfg.accumulate or cfg.arena.prezeroed)
         dbias = dwc = None
     else:
         dbias = K.colsum(dlogits)[:ncls]

@@ -213,6 +213,11 @@ def pack_weight(w, dtype, cout_pad=None, want_fwd=True, want_bwd=True):
     return wf, wb
 
 
+def pack_weight_multi(table, n, dtype):
+    code = BF16 if dtype == torch.bfloat16 else F32
+    check(lib().eeseg_pack_weight_multi(_p(table), n, code, _stream()), "eeseg_pack_weight_multi")
+
+
 def pack_matrix(src, rows_pad, cols_pad, dtype):
     _need_cuda(src)
     rows, cols = src.shape

@@ -181,6 +181,11 @@ class GraphedTrainStep:
         self._bns = [m for m in net.modules() if type(m).__name__ == "BatchNorm2d"]
 
     def _eager(self, X, y):
+        arena = self.net.cfg.arena
+        if arena is not None and not self.net.cfg.accumulate:
+            engine.pack_all(self.net, self.net.cfg.compute_dtype)      # one launch instead of one per conv
+            arena.prezeroed = True                                     # one memset instead of one per wgrad
+            arena.flat.zero_()
         out = self.net(X)
         loss = self.criterion(out, y)
         self.opt.zero_grad(set_to_none=True)
@@ -189,6 +194,8 @@ class GraphedTrainStep:
             self.reducer.finish()
         self.opt.step()
         self.net.cfg.end_step()
+        if arena is not None:
+            arena.prezeroed = False
         return loss.detach()
 
     def __call__(self, X, y):

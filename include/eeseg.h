@@ -83,6 +83,9 @@ int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
  * default [co][ci][r][s]. */
 int eeseg_pack_weight(const float* src, void* w_fwd, void* w_bwd, int Cout, int Cout_pad, int Cin, int R, int S,
                       int src_krsc, int dtype, void* stream);
+/* The same for n weights in ONE launch.  desc_table: device array of n 48-byte records
+ * { const float* src; void* w_fwd; void* w_bwd; int32 Cout, Cout_pad, Cin, taps, src_krsc, pad; }. */
+int eeseg_pack_weight_multi(const void* desc_table, int n, int dtype, void* stream);
 /* fp32 [rows][cols] (row stride ld_src) -> dtype [rows_pad][cols_pad], zero padded
  * (stem weight [64][147] -> [64][192] for the im2col GEMM). */
 int eeseg_pack_matrix(const float* src, int rows, int cols, int ld_src, void* dst, int rows_pad, int cols_pad,
