@@ -40,6 +40,7 @@ SIGNATURES = {
     "eeseg_last_error": (C.c_char_p, []),
     "eeseg_version": (_i, []),
     "eeseg_set_option": (_i, [_i, _i]),
+    "eeseg_set_ew_grid_cap": (_i, [_i]),
     "eeseg_conv_stats_tiles": (_i, [_i, _i, _i]),
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),

@@ -416,9 +416,10 @@ template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
     const bool lin = (p.sdiv == 1) && g_conv_linear;
-    if (g_conv_pipe == 2 && lin) {
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
-    } else {   // the tap-outer form keeps the 1-deep pipeline (the 2-deep one spills there)
+    if (g_conv_pipe == 2) {
+        if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, false>), dim3(grid), dim3(256), 0, st, p);
+    } else {
         if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, true>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, false>), dim3(grid), dim3(256), 0, st, p);
     }

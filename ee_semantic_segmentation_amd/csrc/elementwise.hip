@@ -638,10 +638,11 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* y, const T* x, long
 }
 
 // grid for the column-fixed kernels: total threads must be a multiple of chunks-per-row
+int g_colfixed_cap = 256 * 16;      // eeseg_set_option(EESEG_OPT_EW_GRID_CAP, blocks)
 inline int colfixed_grid(long long rows, int cpr) {
     long long items = rows * cpr;
     long long b = (items + 255) / 256;
-    if (b > 256 * 16) b = 256 * 16;
+    if (b > g_colfixed_cap) b = g_colfixed_cap;
     if (b < 1) b = 1;
     int a = cpr, c = 256;                       // m = cpr / gcd(cpr, 256)
     while (c) { int t = a % c; a = c; c = t; }
@@ -698,14 +699,20 @@ extern "C" int eeseg_pack_weight(const float* src, void* w_fwd, void* w_bwd, int
     return EESEG_OK;
 }
 
+extern "C" int eeseg_set_ew_grid_cap(int blocks) {
+    EESEG_CHECK(blocks >= 64 && blocks <= 65535, EESEG_ERR_ARG, "set_ew_grid_cap: out of range");
+    g_colfixed_cap = blocks;
+    return EESEG_OK;
+}
+
 extern "C" int eeseg_pack_weight_multi(const void* desc_table, int n, int dtype, void* stream) {
     EESEG_CHECK(desc_table && n > 0 && n <= 65535, EESEG_ERR_ARG, "pack_weight_multi: bad argument");
     static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI (48 bytes)");
     if (dtype == EESEG_BF16)
-        hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(32, n), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(128, n), dim3(256), 0, (hipStream_t)stream,
                            (const PackDesc*)desc_table);
     else if (dtype == EESEG_F32)
-        hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(32, n), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(128, n), dim3(256), 0, (hipStream_t)stream,
                            (const PackDesc*)desc_table);
     else
         EESEG_CHECK(false, EESEG_ERR_ARG, "pack_weight_multi: bad dtype");

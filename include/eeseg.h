@@ -40,6 +40,8 @@ int eeseg_version(void);
 enum { EESEG_OPT_CONV_PIPE = 1, EESEG_OPT_CONV_TAP_INNER = 2 /* K order: 0 = taps outer (default), 1 = taps inner (fewer L2 misses,
                                   measured 3% slower end to end on MI355X: the Infinity Cache absorbs the re-reads) */ };
 int eeseg_set_option(int key, int value);
+/* upper bound on the grid of the column-fixed BatchNorm elementwise kernels (tuning) */
+int eeseg_set_ew_grid_cap(int blocks);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision
