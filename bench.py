@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--conv-tap-inner", type=int, default=None, help="override EESEG_OPT_CONV_TAP_INNER (0|1)")
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
+    ap.add_argument("--wgrad-blocks", type=int, default=None)
     args = ap.parse_args()
 
     # RCCL / HIP print banners on stdout: keep fd 1 for the single JSON line only
@@ -124,6 +125,8 @@ def main():
         _eelib().eeseg_set_option(1, args.conv_pipe)
     if args.ew_grid_cap is not None:
         _eelib().eeseg_set_ew_grid_cap(args.ew_grid_cap)
+    if args.wgrad_blocks is not None:
+        _eelib().eeseg_set_wgrad_target_blocks(args.wgrad_blocks)
     C, img, B = args.classes, args.img, args.batch_per_gpu
     torch.manual_seed(0)
     net = branchyDeepv3(None, f"deeplabv3_{args.arch}", args.branches, img, count_branches=False, num_classes=C,

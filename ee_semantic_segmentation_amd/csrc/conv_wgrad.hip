@@ -204,7 +204,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     }
 }
 
+int g_wgrad_target_blocks = 1536;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
+
 }  // namespace
+
+extern "C" int eeseg_set_wgrad_target_blocks(int blocks) {
+    EESEG_CHECK(blocks >= 64 && blocks <= 65535, EESEG_ERR_ARG, "set_wgrad_target_blocks: out of range");
+    g_wgrad_target_blocks = blocks;
+    return EESEG_OK;
+}
 
 extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     EESEG_CHECK(a && a->x && a->dy && a->dw, EESEG_ERR_ARG, "conv_wgrad: null pointer");
@@ -238,7 +246,7 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.dybytes = (uint32_t)dybytes;
     const int kp = 128 / es;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
-    long long splits = (1536 + tiles - 1) / tiles;            // aim at ~6 blocks per CU
+    long long splits = (g_wgrad_target_blocks + tiles - 1) / tiles;
     const long long max_splits = (M + 4 * kp - 1) / (4 * kp); // at least 4 K steps per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -42,6 +42,8 @@ enum { EESEG_OPT_CONV_PIPE = 1, EESEG_OPT_CONV_TAP_INNER = 2 /* K order: 0 = tap
 int eeseg_set_option(int key, int value);
 /* upper bound on the grid of the column-fixed BatchNorm elementwise kernels (tuning) */
 int eeseg_set_ew_grid_cap(int blocks);
+/* split-K sizing of the weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at */
+int eeseg_set_wgrad_target_blocks(int blocks);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision
