@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     }
 }
 
-int g_wgrad_target_blocks = 1536;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
+int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
 
 }  // namespace
 
