@@ -26,6 +26,7 @@ struct ConvP {
     int M, HWout, n_tiles, m_tiles;
     uint32_t xbytes, wbytes;
     int vec_ok;   // 1: 16-byte row stores allowed (alignment / Cout multiple)
+    int tap_inner;   // LINEAR kernels: K order (0 = taps outer / channels inner, 1 = taps inner)
 };
 
 template <typename T> struct Mma;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     uint32_t voffA[4], voffW[WCH];
     int baseA[4];                 // LINEAR: byte offset of the tap-(0,0) source pixel (may be negative)
     unsigned rest = tapmask;
-    int ci = LINEAR ? 0 : kc_steps - 1;      // !LINEAR: forces a tap advance on the first next_tile()
+    int ci = (LINEAR && p.tap_inner) ? 0 : kc_steps - 1;   // tap-outer orders: first next_tile() advances the tap
     int cur_tap = 0, soffA = 0, soffW = 0;
     bool live = nk > 0;
 
@@ -182,17 +183,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             voffW[j] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
         }
     }
+    auto set_tap_linear = [&](int tap) {     // LINEAR: offsets of one tap = base[row] + delta[tap], masked
+        const int r = tap / p.S, s = tap - r * p.S;
+        const int dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            voffA[j] = (live && ((vmask[j] >> tap) & 1u)) ? (uint32_t)(baseA[j] + dtap) : EESEG_OOB;
+    };
     auto next_tile = [&]() {   // block-uniform iterator over the K tiles
         if constexpr (LINEAR) {
-            if (!rest) { rest = tapmask; ++ci; }
-            live = live && ci < kc_steps;
-            cur_tap = __ffs(rest) - 1;
-            rest &= rest - 1;
-            const int r = cur_tap / p.S, s = cur_tap - r * p.S;
-            const int dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * (int)sizeof(T);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                voffA[j] = (live && ((vmask[j] >> cur_tap) & 1u)) ? (uint32_t)(baseA[j] + dtap) : EESEG_OOB;
+            if (p.tap_inner) {                    // channel chunk outer, taps inner
+                if (!rest) { rest = tapmask; ++ci; }
+                live = live && ci < kc_steps;
+                cur_tap = __ffs(rest) - 1;
+                rest &= rest - 1;
+                set_tap_linear(cur_tap);
+            } else if (++ci >= kc_steps) {        // taps outer, channel chunks inner (default)
+                ci = 0;
+                live = live && rest != 0u;
+                cur_tap = rest ? __ffs(rest) - 1 : 0;
+                rest &= rest - 1;
+                set_tap_linear(cur_tap);
+            }
             soffA = ci * ROWB;
             soffW = live ? (cur_tap * p.Cin) * (int)sizeof(T) + ci * ROWB : 0x7FFFFF00;
         } else {
@@ -415,7 +427,7 @@ int g_conv_pipe = 2;     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
 template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
-    const bool lin = (p.sdiv == 1) && g_conv_linear;
+    const bool lin = (p.sdiv == 1);            // linear addressing whenever the source coordinate is linear in the tap
     if (g_conv_pipe == 2) {
         if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, false>), dim3(grid), dim3(256), 0, st, p);
@@ -481,6 +493,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.m_tiles = (int)((M + BM - 1) / BM);
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
+    p.tap_inner = g_conv_linear;
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;
