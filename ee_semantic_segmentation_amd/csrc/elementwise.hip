@@ -49,22 +49,54 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* wf, T* wb, 
 
 // one launch packs every conv weight of the network: desc[t] = {src, w_fwd, w_bwd, Cout, Cout_pad, Cin, taps, krsc}
 struct PackDesc { const float* src; void* wf; void* wb; int Cout, Cout_pad, Cin, taps, krsc, pad_; };
+// KRSC sources go through a 32x32 LDS-tiled transpose so both outputs are written in
+// contiguous runs (the naive scattered 2-byte stores of w_bwd cost 8x write amplification).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackDesc* __restrict__ desc) {
+    __shared__ float tile[32][33];
     const PackDesc d = desc[blockIdx.y];
     T* wf = (T*)d.wf;
     T* wb = (T*)d.wb;
-    const long long total = (long long)d.Cout_pad * d.taps * d.Cin;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
-        const int ci = (int)(i % d.Cin);
-        const long long r = i / d.Cin;
-        const int tap = (int)(r % d.taps);
-        const int co = (int)(r / d.taps);
-        float v = 0.f;
-        if (co < d.Cout) v = d.krsc ? d.src[((long long)co * d.taps + tap) * d.Cin + ci]
-                                    : d.src[((long long)co * d.Cin + ci) * d.taps + tap];
-        if (wf) wf[i] = from_f32<T>(v);
-        if (wb) wb[((long long)ci * d.taps + tap) * d.Cout_pad + co] = from_f32<T>(v);
+    if (!d.krsc) {       // torch-default KCRS source: plain element-wise path
+        const long long total = (long long)d.Cout_pad * d.taps * d.Cin;
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += gridDim.x * 256ll) {
+            const int ci = (int)(i % d.Cin);
+            const long long r = i / d.Cin;
+            const int tap = (int)(r % d.taps);
+            const int co = (int)(r / d.taps);
+            const float v = (co < d.Cout) ? d.src[((long long)co * d.Cin + ci) * d.taps + tap] : 0.f;
+            if (wf) wf[i] = from_f32<T>(v);
+            if (wb) wb[((long long)ci * d.taps + tap) * d.Cout_pad + co] = from_f32<T>(v);
+        }
+        return;
+    }
+    const int tco = (d.Cout_pad + 31) / 32, tci = (d.Cin + 31) / 32;
+    const int ntiles = tco * tci * d.taps;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tap = t % d.taps;
+        const int tc = (t / d.taps) % tci;
+        const int to = t / (d.taps * tci);
+        const int ci = tc * 32 + tx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = to * 32 + ty + 8 * k;
+            float v = 0.f;
+            if (co < d.Cout && ci < d.Cin) v = d.src[((long long)co * d.taps + tap) * d.Cin + ci];
+            tile[ty + 8 * k][tx] = v;
+            if (wf && co < d.Cout_pad && ci < d.Cin) wf[((long long)co * d.taps + tap) * d.Cin + ci] = from_f32<T>(v);
+        }
+        __syncthreads();
+        if (wb) {
+            const int co = to * 32 + tx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c2 = tc * 32 + ty + 8 * k;
+                if (co < d.Cout_pad && c2 < d.Cin)
+                    wb[((long long)c2 * d.taps + tap) * d.Cout_pad + co] = from_f32<T>(tile[tx][ty + 8 * k]);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -710,10 +742,10 @@ extern "C" int eeseg_pack_weight_multi(const void* desc_table, int n, int dtype,
     EESEG_CHECK(desc_table && n > 0 && n <= 65535, EESEG_ERR_ARG, "pack_weight_multi: bad argument");
     static_assert(sizeof(PackDesc) == 48, "PackDesc layout is part of the ABI (48 bytes)");
     if (dtype == EESEG_BF16)
-        hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(128, n), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(96, n), dim3(256), 0, (hipStream_t)stream,
                            (const PackDesc*)desc_table);
     else if (dtype == EESEG_F32)
-        hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(128, n), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(96, n), dim3(256), 0, (hipStream_t)stream,
                            (const PackDesc*)desc_table);
     else
         EESEG_CHECK(false, EESEG_ERR_ARG, "pack_weight_multi: bad dtype");

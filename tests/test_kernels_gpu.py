@@ -393,3 +393,28 @@ def test_lovasz_edge_cases():
         got.backward()
         assert abs(got.item() - want.item()) < 3e-6 * max(1.0, abs(want.item())), shape
         close(yd.grad, yr.grad, 1e-3, f"lovasz grad {shape}")      # gradients are O(1e-4): 1 ulp = 3e-4 rel
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_pack_weight_multi_matches_single(dtype):
+    """The one-launch multi-tensor pack (LDS-tiled transpose) == per-tensor packs, incl. odd
+    shapes, class padding and a torch-default (KCRS) 3x3 source."""
+    import numpy as np
+    ws = [torch.randn(70, 64, 3, 3).contiguous(memory_format=torch.channels_last), torch.randn(21, 256, 1, 1),
+          torch.randn(64, 128, 3, 3), torch.randn(256, 1280, 1, 1)]
+    pads = [None, 32, None, None]
+    dev = [w.to(DEV) for w in ws]
+    rec = np.zeros((len(ws), 6), dtype=np.int64)
+    outs = []
+    for i, (w, cp) in enumerate(zip(dev, pads)):
+        co, ci, r, s_ = w.shape
+        cpad = cp or co
+        krsc = 1 if (w.is_contiguous(memory_format=torch.channels_last) or (r == 1 and s_ == 1)) else 0
+        wf = torch.full((cpad, r, s_, ci), 7.0, dtype=dtype, device=DEV)
+        wb = torch.full((ci, r, s_, cpad), 7.0, dtype=dtype, device=DEV)
+        outs.append((wf, wb))
+        rec[i] = [w.data_ptr(), wf.data_ptr(), wb.data_ptr(), co | (cpad << 32), ci | ((r * s_) << 32), krsc]
+    K.pack_weight_multi(torch.from_numpy(rec).to(DEV), len(ws), dtype)
+    for w, cp, (wf, wb) in zip(dev, pads, outs):
+        rf, rb = K.pack_weight(w, dtype, cp)
+        assert torch.equal(wf, rf) and torch.equal(wb, rb)
