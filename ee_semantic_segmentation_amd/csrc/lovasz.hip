@@ -2,21 +2,16 @@
 // lovaszsoftmax.py:172-200, per_image=False, classes='present'), fully on device:
 //   1. prep : key[c][p] = |1[y_p=c] - s_pc| (valid pixels) or -1 (void: sorts last),
 //             val = pixel index | sign bit;  class pixel counts G[c], #valid pixels
-//   2. sort : rocPRIM segmented radix sort, descending, one segment per class
-//             (the sort is the only non-hand-written device code in libeeseg; a
-//             hand-written LDS radix sort is the planned replacement)
+//   2. sort : hand-written segmented LSD radix sort (4 passes of 8 bits, descending, one
+//             segment per class): per-tile LDS histograms -> per-class scan of the
+//             (digit, tile) counts -> stable scatter with wave-ballot digit matching
 //   3. scan : per class, blocked inclusive scan of the sorted foreground flags ->
 //             Jaccard gradient J_k - J_{k-1} (lovasz_grad, lovaszsoftmax.py:19-31),
 //             loss_c = sum e_k * grad_k, and d(loss)/d(score) scattered back through
 //             the permutation.  Loss = mean over classes present in the labels.
 // No host synchronisation: counts, #present classes and the upstream gradient scalar
 // are read from device memory.
-#include <cstring>
-#include <string.h>
-
 #include "eeseg_common.h"
-
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 namespace {
 
@@ -65,9 +60,105 @@ __global__ __launch_bounds__(256) void lv_prep(const float* __restrict__ scores,
     if (threadIdx.x == 0 && sValid) atomicAdd(&hdr->n_valid, sValid);
 }
 
-__global__ void lv_offsets(unsigned* offs, int C, long long P) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= C) offs[i] = (unsigned)((long long)i * P);
+// ------------------------------------------------------------------ radix sort ----
+// Keys are floats >= 0 or -1; descending float order == ascending order of
+// ukey = ~(sign-flipped bits).  One pass sorts by 8 bits, least significant first.
+constexpr int RT = 4096;            // elements per sort tile (256 threads x 16)
+
+__device__ __forceinline__ unsigned sort_key(float f) {
+    unsigned u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending unsigned == ascending float
+    return ~u;                                          // descending float
+}
+
+// hist[c][digit][tile] = number of elements of tile with that digit
+__global__ __launch_bounds__(256) void rs_hist(const float* __restrict__ keys, long long P, int ntile, int shift,
+                                               unsigned* __restrict__ hist) {
+    __shared__ unsigned sh[256];
+    const int c = blockIdx.y, t = blockIdx.x;
+    sh[threadIdx.x] = 0u;
+    __syncthreads();
+    const long long base = (long long)t * RT;
+    for (int i = threadIdx.x; i < RT; i += 256) {
+        const long long k = base + i;
+        if (k < P) atomicAdd(&sh[(sort_key(keys[(size_t)c * P + k]) >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[((size_t)c * 256 + threadIdx.x) * ntile + t] = sh[threadIdx.x];
+}
+
+// exclusive scan of hist[c][:] (256*ntile entries, digit-major) in place; one block per class
+__global__ __launch_bounds__(1024) void rs_scan(unsigned* hist, int n) {
+    __shared__ unsigned swave[16];
+    __shared__ unsigned carry;
+    unsigned* h = hist + (size_t)blockIdx.x * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (int b = 0; b < n; b += 1024) {
+        const int i = b + threadIdx.x;
+        const unsigned v = (i < n) ? h[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) swave[wave] = incl;
+        __syncthreads();
+        unsigned off = carry;
+        for (int w = 0; w < wave; ++w) off += swave[w];
+        if (i < n) h[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + incl;
+        __syncthreads();
+    }
+}
+
+// stable scatter: element -> hist[c][digit][tile] + (rank among the tile's earlier elements with that digit)
+__global__ __launch_bounds__(256) void rs_scatter(const float* __restrict__ kin, const unsigned* __restrict__ vin,
+                                                  float* __restrict__ kout, unsigned* __restrict__ vout, long long P,
+                                                  int ntile, int shift, const unsigned* __restrict__ hist) {
+    __shared__ unsigned sbase[256];         // running output position per digit
+    __shared__ unsigned scnt[4][256];       // per-wave digit counts of the current 256-element round
+    const int c = blockIdx.y, t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sbase[threadIdx.x] = hist[((size_t)c * 256 + threadIdx.x) * ntile + t];
+    const long long base = (long long)t * RT;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < RT / 256; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) scnt[w][threadIdx.x] = 0u;
+        __syncthreads();
+        const long long k = base + r * 256 + threadIdx.x;      // wave w owns 64 consecutive elements: stable
+        const bool ok = k < P;
+        float key = 0.f;
+        unsigned val = 0u, dg = 0u;
+        if (ok) {
+            key = kin[(size_t)c * P + k];
+            val = vin[(size_t)c * P + k];
+            dg = (sort_key(key) >> shift) & 255u;
+        }
+        // lanes of this wave holding the same digit (8 ballots), inactive lanes excluded
+        unsigned long long same = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((dg >> b) & 1u);
+            same &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const unsigned rank_in_wave = (unsigned)__popcll(same & below);
+        if (ok && rank_in_wave == 0) scnt[wave][dg] = (unsigned)__popcll(same);      // one writer per (wave, digit)
+        __syncthreads();
+        if (ok) {
+            unsigned off = sbase[dg] + rank_in_wave;
+            for (int w = 0; w < wave; ++w) off += scnt[w][dg];
+            kout[(size_t)c * P + off] = key;
+            vout[(size_t)c * P + off] = val;
+        }
+        __syncthreads();
+        sbase[threadIdx.x] += scnt[0][threadIdx.x] + scnt[1][threadIdx.x] + scnt[2][threadIdx.x] + scnt[3][threadIdx.x];
+        __syncthreads();
+    }
 }
 
 // per (class, block): number of foreground elements among the first n_valid sorted entries
@@ -188,42 +279,33 @@ __global__ void lv_loss(const double* class_loss, const int* G, int C, const LvH
 }
 
 struct Layout {
-    size_t hdr, G, closs, offs, bsum, keys_in, keys_out, vals_in, vals_out, temp, total;
+    size_t hdr, G, closs, bsum, hist, keys_in, keys_out, vals_in, vals_out, total;
 };
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-Layout layout(long long P, int C, size_t temp_bytes) {
+Layout layout(long long P, int C) {
     const int nblk = (int)((P + SB - 1) / SB);
+    const int ntile = (int)((P + RT - 1) / RT);
     Layout L;
     size_t o = 0;
     L.hdr = o; o += 256;
     L.G = o; o += align256((size_t)C * 4);
     L.closs = o; o += align256((size_t)C * 8);
-    L.offs = o; o += align256((size_t)(C + 1) * 4);
     L.bsum = o; o += align256((size_t)C * nblk * 4);
+    L.hist = o; o += align256((size_t)C * 256 * ntile * 4);
     const size_t arr = align256((size_t)C * P * 4);
     L.keys_in = o; o += arr;
     L.keys_out = o; o += arr;
     L.vals_in = o; o += arr;
     L.vals_out = o; o += arr;
-    L.temp = o; o += align256(temp_bytes);
     L.total = o;
     return L;
-}
-
-size_t sort_temp_bytes(long long P, int C) {
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs_desc((void*)nullptr, bytes, (const float*)nullptr, (float*)nullptr,
-                                             (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned)(C * P), (unsigned)C,
-                                             (const unsigned*)nullptr, (const unsigned*)nullptr, 0, 32,
-                                             (hipStream_t)0, false);
-    return bytes;
 }
 
 }  // namespace
 
 extern "C" int64_t eeseg_lovasz_workspace(int64_t P, int C) {
     if (P <= 0 || C <= 0 || (long long)P * C >= (1ll << 31)) return -1;
-    return (int64_t)layout(P, C, sort_temp_bytes(P, C)).total;
+    return (int64_t)layout(P, C).total;
 }
 
 extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
@@ -233,15 +315,14 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     EESEG_CHECK(N > 0 && C > 0 && C <= 64 && HW > 0, EESEG_ERR_ARG, "lovasz: bad shape (C <= 64)");
     const long long P = (long long)N * HW;
     EESEG_CHECK(P * C < (1ll << 31), EESEG_ERR_TOO_LARGE, "lovasz: N*HW*C must be < 2^31");
-    size_t temp = sort_temp_bytes(P, C);
-    const Layout L = layout(P, C, temp);
+    const Layout L = layout(P, C);
     EESEG_CHECK(workspace_bytes >= (int64_t)L.total, EESEG_ERR_ARG, "lovasz: workspace too small (%zu needed)", L.total);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)workspace;
     LvHeader* hdr = (LvHeader*)(w + L.hdr);
     int* G = (int*)(w + L.G);
     double* closs = (double*)(w + L.closs);
-    unsigned* offs = (unsigned*)(w + L.offs);
+    unsigned* hist = (unsigned*)(w + L.hist);
     int* bsum = (int*)(w + L.bsum);
     float* keys_in = (float*)(w + L.keys_in);
     float* keys_out = (float*)(w + L.keys_out);
@@ -249,18 +330,28 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     unsigned* vals_out = (unsigned*)(w + L.vals_out);
     const int nblk = (int)((P + SB - 1) / SB);
 
-    EESEG_HIP(hipMemsetAsync(w, 0, L.offs, st));                       // header, G, class losses
+    EESEG_HIP(hipMemsetAsync(w, 0, L.bsum, st));                       // header, G, class losses
     if (dscores) EESEG_HIP(hipMemsetAsync(dscores, 0, (size_t)P * C * sizeof(float), st));
     long long pb = (P + 255) / 256;
     if (pb > 4096) pb = 4096;
     hipLaunchKernelGGL(lv_prep, dim3((unsigned)pb), dim3(256), 0, st, scores, target, N, C, HW, (long long)ignore_index,
                        keys_in, vals_in, G, hdr);
-    hipLaunchKernelGGL(lv_offsets, dim3(1), dim3(128), 0, st, offs, C, P);
     EESEG_LAUNCH_CHECK();
-    hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)(w + L.temp), temp, keys_in, keys_out, vals_in, vals_out,
-                                                            (unsigned)(C * P), (unsigned)C, offs, offs + 1, 0, 32, st,
-                                                            false);
-    EESEG_CHECK(e == hipSuccess, EESEG_ERR_HIP, "lovasz: segmented sort failed: %s", hipGetErrorString(e));
+    // 4 x 8-bit LSD passes, ping-pong between the two buffer pairs
+    const int ntile = (int)((P + RT - 1) / RT);
+    float* ka = keys_in; float* kb = keys_out;
+    unsigned* va = vals_in; unsigned* vb = vals_out;
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(rs_hist, dim3(ntile, C), dim3(256), 0, st, (const float*)ka, P, ntile, pass * 8, hist);
+        hipLaunchKernelGGL(rs_scan, dim3(C), dim3(1024), 0, st, hist, 256 * ntile);
+        hipLaunchKernelGGL(rs_scatter, dim3(ntile, C), dim3(256), 0, st, (const float*)ka, (const unsigned*)va, kb, vb, P,
+                           ntile, pass * 8, (const unsigned*)hist);
+        float* tk = ka; ka = kb; kb = tk;
+        unsigned* tv = va; va = vb; vb = tv;
+    }
+    EESEG_LAUNCH_CHECK();
+    keys_out = ka;                 // after an even number of passes the sorted data is back in the first pair
+    vals_out = va;
     hipLaunchKernelGGL(lv_block_counts, dim3(nblk, C), dim3(256), 0, st, vals_out, target, P, nblk, hdr, bsum);
     hipLaunchKernelGGL(lv_scan_blocks, dim3(1), dim3(64), 0, st, bsum, nblk, C, G, hdr);
     hipLaunchKernelGGL(lv_final, dim3(nblk, C), dim3(256), 0, st, keys_out, vals_out, target, P, nblk, C, HW, G, bsum, hdr,
