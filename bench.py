@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
+    ap.add_argument("--no-overlap-wgrad", action="store_true")
     args = ap.parse_args()
 
     # RCCL / HIP print banners on stdout: keep fd 1 for the single JSON line only
@@ -133,6 +134,7 @@ def main():
                         compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
                         fused_outputs=True).to(dev)
     net.cfg.sync_bn = args.sync_bn and world > 1
+    net.cfg.overlap_wgrad = not args.no_overlap_wgrad
     broadcast_parameters(net)
     E = net.n_branches + 1
     crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)

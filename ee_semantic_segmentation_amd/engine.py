@@ -37,6 +37,8 @@ class Config:
         self.accumulate = False              # arena mode: add to the stored gradients instead of overwriting
         self.step_counter = None             # device int64[1]; lets a captured graph draw fresh dropout masks
         self.on_unit_done = None             # callable(unit_id): gradient bucket scheduling (GradReducer)
+        self.overlap_wgrad = True            # weight-gradient on a side stream, concurrent with the data-gradient:
+        self._side = None                    # the two kernels fill each other's partially filled last block round
 
     def world(self):
         return dist.get_world_size(self.group) if (self.sync_bn and dist.is_initialized()) else 1
@@ -54,6 +56,11 @@ class Config:
         """Advance the device-side step counter (captured into training graphs)."""
         if self.step_counter is not None:
             self.step_counter.add_(1)
+
+    def side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def gview(self, param):
         return None if self.arena is None else self.arena.kernel_view.get(param)
@@ -274,15 +281,30 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         return None, dres, dwk.reshape(cout, r, s_, cin).permute(0, 3, 1, 2), dgamma, dbeta
     s, p, d = _geom(conv)
     R, S = conv.weight.shape[2], conv.weight.shape[3]
-    if gv is not None:
-        K.conv_wgrad(x, dc, R, S, s, p, d, out=gv, accumulate=cfg.accumulate or cfg.arena.prezeroed)
-        dwp = None
-    else:
-        dwp = K.conv_wgrad(x, dc, R, S, s, p, d).permute(0, 3, 1, 2)
+
+    def wgrad():
+        if gv is not None:
+            K.conv_wgrad(x, dc, R, S, s, p, d, out=gv, accumulate=cfg.accumulate or cfg.arena.prezeroed)
+            return None
+        return K.conv_wgrad(x, dc, R, S, s, p, d).permute(0, 3, 1, 2)
+
     dx = None
-    if need_dx:
+    if need_dx and cfg.overlap_wgrad and dc.is_cuda:
+        # fork: wgrad on the side stream, dgrad on the current one, join right after - both kernels
+        # are in flight together and every later consumer is ordered after both
+        cur = torch.cuda.current_stream(dc.device)
+        side = cfg.side_stream(dc.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            dwp = wgrad()
         _, wb = packed(conv, dc.dtype)
         dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+        cur.wait_stream(side)
+    else:
+        dwp = wgrad()
+        if need_dx:
+            _, wb = packed(conv, dc.dtype)
+            dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
     return dx, dres, dwp, dgamma, dbeta
 
 
