@@ -39,6 +39,8 @@ class Config:
         self.on_unit_done = None             # callable(unit_id): gradient bucket scheduling (GradReducer)
         self.overlap_wgrad = True            # weight-gradient on a side stream, concurrent with the data-gradient:
         self._side = None                    # the two kernels fill each other's partially filled last block round
+        self._side_busy = False
+        self._side_keep = []                 # tensors the side stream still reads (freed after the join)
 
     def world(self):
         return dist.get_world_size(self.group) if (self.sync_bn and dist.is_initialized()) else 1
@@ -62,10 +64,18 @@ class Config:
             self._side = torch.cuda.Stream(device=device)
         return self._side
 
+    def join_side(self):
+        """Make the current stream wait for the weight-gradient kernels issued on the side stream."""
+        if self._side_busy:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side_busy = False
+            self._side_keep.clear()
+
     def gview(self, param):
         return None if self.arena is None else self.arena.kernel_view.get(param)
 
     def unit_done(self, module):
+        self.join_side()                     # the unit's weight gradients are complete from here on
         if self.on_unit_done is not None:
             uid = module.__dict__.get("_eeseg_unit")
             if uid is not None:
@@ -290,16 +300,18 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
 
     dx = None
     if need_dx and cfg.overlap_wgrad and dc.is_cuda:
-        # fork: wgrad on the side stream, dgrad on the current one, join right after - both kernels
-        # are in flight together and every later consumer is ordered after both
+        # fork: wgrad goes to the side stream and runs concurrently with the data-gradient and the
+        # following BatchNorm-backward kernels of this unit; Config.unit_done() joins.  The tensors it
+        # reads are kept alive until then so the allocator cannot hand their memory out early.
         cur = torch.cuda.current_stream(dc.device)
         side = cfg.side_stream(dc.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             dwp = wgrad()
+        cfg._side_busy = True
+        cfg._side_keep.append((x, dc, dwp))
         _, wb = packed(conv, dc.dtype)
         dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
-        cur.wait_stream(side)
     else:
         dwp = wgrad()
         if need_dx:

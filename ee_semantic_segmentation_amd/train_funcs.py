@@ -28,6 +28,8 @@ def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runn
         l = loss(y_hat, y)
         updater.zero_grad()
         l.mean().backward()
+        if hasattr(net, "cfg"):
+            net.cfg.join_side()
         updater.step()
         if hasattr(net, "cfg"):
             net.cfg.end_step()
