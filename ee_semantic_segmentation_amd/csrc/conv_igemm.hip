@@ -95,6 +95,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 
     // ---- per-thread gather rows (fixed for the whole K loop) -----------------
     const int lrow = tid >> 3, lchunk = tid & 7;
+    // PIPE == 0: tiles are staged by LDS-DMA (buffer_load ... lds): the LDS image is lane-linear, so the XOR
+    // swizzle moves to the SOURCE chunk each lane fetches (rows lrow+32j share (row>>1)&7)
+    constexpr bool DMA = (PIPE == 0);
+    const int gchunk = DMA ? (lchunk ^ ((lrow >> 1) & 7)) : lchunk;
     int hb[4], wb[4], nb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -166,21 +170,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
             int hi = 0, wi = 0;
             const bool ok = map_coord(hb[j], r, p.tstep_h, p.sdiv, p.Hin, hi) &&
                             map_coord(wb[j], s, p.tstep_w, p.sdiv, p.Win, wi);
-            voffA[j] = ok ? (uint32_t)(((nb[j] + hi * p.Win + wi) * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
+            voffA[j] = ok ? (uint32_t)(((nb[j] + hi * p.Win + wi) * p.Cin) * (int)sizeof(T) + gchunk * 16) : EESEG_OOB;
         }
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
             const int co = n0 + lrow + 32 * j;
-            voffW[j] = (co < p.Cout) ? (uint32_t)(((co * taps + tap) * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
+            voffW[j] = (co < p.Cout) ? (uint32_t)(((co * taps + tap) * p.Cin) * (int)sizeof(T) + gchunk * 16) : EESEG_OOB;
         }
     };
     if constexpr (LINEAR) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) baseA[j] = ((nb[j] + hb[j] * p.Win + wb[j]) * p.Cin) * (int)sizeof(T) + lchunk * 16;
+        for (int j = 0; j < 4; ++j) baseA[j] = ((nb[j] + hb[j] * p.Win + wb[j]) * p.Cin) * (int)sizeof(T) + gchunk * 16;
 #pragma unroll
         for (int j = 0; j < WCH; ++j) {
             const int co = n0 + lrow + 32 * j;
-            voffW[j] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * (int)sizeof(T) + lchunk * 16) : EESEG_OOB;
+            voffW[j] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * (int)sizeof(T) + gchunk * 16) : EESEG_OOB;
         }
     }
     auto set_tap_linear = [&](int tap) {     // LINEAR: offsets of one tap = base[row] + delta[tap], masked
@@ -243,6 +247,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
         }
     };
 
+    auto dma_tile = [&](int buf) {    // one 1-KiB wave-instruction = 8 rows x 128 B, LDS dest = uniform base + lane*16
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const int w8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sX + buf * BM * ROWB + (32 * j + w8) * ROWB), 16,
+                                                     (int)voffA[j], soffA, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WCH; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sW + buf * BN * ROWB + (32 * j + w8) * ROWB), 16,
+                                                     (int)voffW[j], soffW, 0, 0);
+    };
+
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
     const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
 
@@ -268,7 +285,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     // before computing tile k, so every global load has two compute phases to land.  Loads and
     // LDS stores are unconditional (tiles past the end are out-of-range zero loads) so the
     // compiler's counted s_waitcnt vmcnt leaves the 8 newest loads in flight.
-    if constexpr (PIPE == 2) {
+    if constexpr (DMA) {
+        // 1-deep: the DMA of tile k+1 flies during compute(k); __syncthreads() drains vmcnt(0) before the
+        // barrier (hipcc treats an in-flight LDS-DMA as a pending LDS write), so no counted waits are needed
+        next_tile();
+        dma_tile(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            next_tile();
+            dma_tile(cur ^ 1);
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else if constexpr (PIPE == 2) {
         next_tile();
         load_tile(ra0, rw0);
         store_tile(0, ra0, rw0);
@@ -428,12 +459,14 @@ template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
     const bool lin = (p.sdiv == 1);            // linear addressing whenever the source coordinate is linear in the tap
-    if (g_conv_pipe == 2) {
-        if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, false>), dim3(grid), dim3(256), 0, st, p);
-    } else {
-        if (lin) hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, true>), dim3(grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, false>), dim3(grid), dim3(256), 0, st, p);
+    if (lin && g_conv_pipe == 0) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 0, true>), dim3(grid), dim3(256), 0, st, p);
+    } else if (lin && g_conv_pipe == 2) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
+    } else if (lin) {
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, true>), dim3(grid), dim3(256), 0, st, p);
+    } else {   // strided data-gradient: register staging, 1-deep (the 2-deep form spills there)
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 1, false>), dim3(grid), dim3(256), 0, st, p);
     }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
@@ -442,7 +475,7 @@ int launch(const ConvP& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int eeseg_set_option(int key, int value) {
-    if (key == EESEG_OPT_CONV_PIPE && (value == 1 || value == 2)) {
+    if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 2)) {
         g_conv_pipe = value;
         return EESEG_OK;
     }

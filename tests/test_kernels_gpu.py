@@ -418,3 +418,18 @@ def test_pack_weight_multi_matches_single(dtype):
     for w, cp, (wf, wb) in zip(dev, pads, outs):
         rf, rb = K.pack_weight(w, dtype, cp)
         assert torch.equal(wf, rf) and torch.equal(wb, rb)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("pipe", [0, 1], ids=["lds_dma", "pipe1"])
+def test_conv_alternate_pipelines(pipe, dtype):
+    """The LDS-DMA staged K loop (EESEG_OPT_CONV_PIPE=0) and the 1-deep register pipeline give
+    the same results as the default 2-deep one (padding taps = zero-filled DMA lanes included)."""
+    from ee_semantic_segmentation_amd._lib import lib
+    lib().eeseg_set_option(1, pipe)
+    try:
+        for case in [(2, 13, 11, 64, 128, 3, 1, 1, 1), (1, 17, 17, 128, 256, 3, 1, 12, 12), (3, 17, 13, 128, 64, 1, 1, 0, 1),
+                     (2, 15, 14, 64, 128, 3, 2, 1, 1)]:
+            test_conv_fwd_dgrad_wgrad(case, dtype)
+    finally:
+        lib().eeseg_set_option(1, 2)
