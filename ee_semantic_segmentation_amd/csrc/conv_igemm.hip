@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
 }
 
 int g_conv_linear = 0;   // eeseg_set_option(EESEG_OPT_CONV_TAP_INNER, 0|1)
-int g_conv_pipe = 2;     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
+int g_conv_pipe = 0;     // LDS-DMA staging (A/B on MI355X: +3.5 % end to end over the 2-deep register pipeline)     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
 
 template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
