@@ -7,10 +7,6 @@
 //   takes one k per lane) reads plain dwords.
 // Tile: 128 couts x 128 cins x (64 bf16 / 32 f32) pixels per step, 4 waves of
 //   64x64; split-K over pixel ranges, fp32 atomics into dW (KRSC, fp32).
-// Staging: LDS-DMA (buffer_load ... lds).  One pixel row per thread; the LDS image is
-//   [chunk group g][pixel row][SEGB bytes] (SEGB = 64 B bf16 / 128 B f32 = the bytes one row's
-//   threads fetch per instruction), which is exactly lane-linear for the DMA and keeps the
-//   transposing reads bank-conflict free without a swizzle.
 #include "eeseg_common.h"
 
 namespace {
@@ -50,13 +46,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     const int pe = min(p.M, ps + p.chunk);
     const int nk = (pe > ps) ? (pe - ps + KP - 1) / KP : 0;
 
-    // one pixel row per thread (KP rows x TPR threads), chunks cb + TPR*i, i = 0..3: a single running
-    // (n, ho, wo) and one validity test per K step
+    // one pixel row per thread (KP rows x TPR threads), 4 chunks interleaved over the row's threads
+    // (chunk = t + TPR*i: each load/LDS-store instruction covers a contiguous run per row, conflict
+    // free): a single running (n, ho, wo) and one validity test per K step.
     constexpr int TPR = CPRW / 4;            // threads per row (4 bf16 / 8 f32); 256 / TPR == KP rows
-    constexpr int SEGB = TPR * 16;           // bytes of one row inside one chunk group (64 / 128)
-    constexpr int RPW = 64 / TPR;            // rows covered by one wave instruction (16 / 8)
     const int lrow = tid / TPR;
-    const int cb = tid % TPR;
+    const int cb = tid % TPR;                // chunks cb + TPR*i, i = 0..3
     int pm = ps + lrow;
     int pn = pm / p.HWout;
     int prem = pm - pn * p.HWout;
@@ -64,30 +59,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     int pw = prem - ph * p.Wout;
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
-    bool co_ok[4], ci_ok[4];                 // per-chunk channel validity (tails of Cout / Cin tiles)
+    // per-chunk channel validity (tails of Cout / Cin tiles)
+    bool co_ok[4], ci_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         co_ok[i] = (co0 + (cb + TPR * i) * EPC) < p.Cout;
         ci_ok[i] = (ci0 + (cb + TPR * i) * EPC) < p.Cin;
     }
-    // byte offset of (pixel row, channel byte) in the LDS image
-    auto lds_off = [](int row, int chbyte) { return (chbyte / SEGB) * (KP * SEGB) + row * SEGB + (chbyte % SEGB); };
 
-    auto dma_tile = [&](int buf) {
-        typedef __attribute__((address_space(3))) void* lds_ptr;
+    i32x4 rdyv[4], rxv[4];
+    auto load_tile = [&]() {
         const bool in = pm < pe;
         const uint32_t based = in ? (uint32_t)((pm * p.lddy + co0) * ES + cb * 16) : EESEG_OOB;
         const int hi = ph * p.stride + dh, wi = pw * p.stride + dwv;
         const bool ok = in && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
         const uint32_t basex = ok ? (uint32_t)((((pn * p.Hin + hi) * p.Win + wi) * p.Cin + ci0) * ES + cb * 16)
                                   : EESEG_OOB;
-        const int wbase = __builtin_amdgcn_readfirstlane(wave) * RPW * SEGB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(sDY + buf * TILE + i * (KP * SEGB) + wbase), 16,
-                                                     (int)(co_ok[i] ? based + i * SEGB : EESEG_OOB), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sX + buf * TILE + i * (KP * SEGB) + wbase), 16,
-                                                     (int)(ci_ok[i] ? basex + i * SEGB : EESEG_OOB), 0, 0, 0);
+            rdyv[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)(co_ok[i] ? based + i * (TPR * 16) : EESEG_OOB), 0, 0);
+            rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ci_ok[i] ? basex + i * (TPR * 16) : EESEG_OOB), 0, 0);
         }
     };
     auto advance = [&]() {
@@ -95,6 +86,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
         pw += KP;
         while (pw >= p.Wout) { pw -= p.Wout; ph += 1; }
         while (ph >= p.Hout) { ph -= p.Hout; pn += 1; }
+    };
+    auto store_tile = [&](int buf) {
+        const int sw = (lrow & 3) << 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lrow * ROWW + (((cb + TPR * i) * 16) ^ sw);
+            *reinterpret_cast<i32x4*>(sDY + buf * TILE + o) = rdyv[i];
+            *reinterpret_cast<i32x4*>(sX + buf * TILE + o) = rxv[i];
+        }
     };
 
     f32x16 acc[2][2];
@@ -106,13 +106,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int wr = wave >> 1, wcI = wave & 1;     // cout half, cin half
-    if (nk > 0) dma_tile(0);
-    __syncthreads();                          // drains the DMA (vmcnt(0)) before the barrier
+    if (nk > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {                    // block-uniform
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
             advance();
-            dma_tile(cur ^ 1);
+            load_tile();
         }
         const char* a = sDY + cur * TILE;
         const char* b = sX + cur * TILE;
@@ -120,26 +124,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             // transposing reads: lane l of each 16-lane group addresses row q=(l>>2)&3, 4 channels at 4*(l&3)
             const int q = (lane >> 2) & 3;
             const int chl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+            const int sw = q << 6;
 #pragma unroll
             for (int ks = 0; ks < KP / 16; ++ks) {
                 bf16x8 af[2], bfr[2];
                 const int row0 = ks * 16 + 8 * (lane >> 5) + q;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int o = lds_off(row0, (wr * 64 + i * 32 + chl) * 2);
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + o));
+                    const int cb = ((wr * 64 + i * 32 + chl) * 2) ^ sw;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a + row0 * ROWW + cb));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a + o + 4 * SEGB));
+                        (__attribute__((address_space(3))) s16x4*)(a + (row0 + 4) * ROWW + cb));
                     union { s16x4 h[2]; bf16x8 v; } u;
                     u.h[0] = lo; u.h[1] = hi;
                     af[i] = u.v;
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int o = lds_off(row0, (wcI * 64 + j * 32 + chl) * 2);
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + o));
+                    const int cb = ((wcI * 64 + j * 32 + chl) * 2) ^ sw;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(b + row0 * ROWW + cb));
                     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(b + o + 4 * SEGB));
+                        (__attribute__((address_space(3))) s16x4*)(b + (row0 + 4) * ROWW + cb));
                     union { s16x4 h[2]; bf16x8 v; } u;
                     u.h[0] = lo; u.h[1] = hi;
                     bfr[j] = u.v;
@@ -155,13 +162,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
 #pragma unroll 4
             for (int kk = 0; kk < KP / 2; ++kk) {
                 const int row = 2 * kk + fh;
+                const int sw = (row & 3) << 6;
                 float av[2], bv[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    av[i] = *reinterpret_cast<const float*>(a + lds_off(row, (wr * 64 + i * 32 + fr) * 4));
+                    av[i] = *reinterpret_cast<const float*>(a + row * ROWW + (((wr * 64 + i * 32 + fr) * 4) ^ sw));
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bv[j] = *reinterpret_cast<const float*>(b + lds_off(row, (wcI * 64 + j * 32 + fr) * 4));
+                    bv[j] = *reinterpret_cast<const float*>(b + row * ROWW + (((wcI * 64 + j * 32 + fr) * 4) ^ sw));
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (has_next) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
