@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
-    ap.add_argument("--no-overlap-wgrad", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="run weight-gradient kernels on a side stream (+1%%; per-kernel timings then overlap)")
     args = ap.parse_args()
 
     # RCCL / HIP print banners on stdout: keep fd 1 for the single JSON line only
@@ -134,7 +135,7 @@ def main():
                         compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
                         fused_outputs=True).to(dev)
     net.cfg.sync_bn = args.sync_bn and world > 1
-    net.cfg.overlap_wgrad = not args.no_overlap_wgrad
+    net.cfg.overlap_wgrad = args.overlap_wgrad
     broadcast_parameters(net)
     E = net.n_branches + 1
     crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)
@@ -179,6 +180,7 @@ def main():
     prof = None
     prof_steps = 0
     if not args.no_kernel_events and rank == 0 or (not args.no_kernel_events and world > 1):
+        net.cfg.overlap_wgrad = False          # per-kernel events need a serial timeline
         K.PROFILE = []
         for _ in range(args.roofline_steps):
             runner._eager(X, y)
