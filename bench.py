@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
+    ap.add_argument("--conv-narrow-max", type=int, default=None)
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="run weight-gradient kernels on a side stream (+1%%; per-kernel timings then overlap)")
     args = ap.parse_args()
@@ -127,6 +128,8 @@ def main():
         _eelib().eeseg_set_option(1, args.conv_pipe)
     if args.ew_grid_cap is not None:
         _eelib().eeseg_set_ew_grid_cap(args.ew_grid_cap)
+    if args.conv_narrow_max is not None:
+        _eelib().eeseg_set_option(3, args.conv_narrow_max)
     if args.wgrad_blocks is not None:
         _eelib().eeseg_set_wgrad_target_blocks(args.wgrad_blocks)
     C, img, B = args.classes, args.img, args.batch_per_gpu
