@@ -43,7 +43,16 @@ class Config:
         self._side_keep = []                 # tensors the side stream still reads (freed after the join)
 
     def world(self):
-        return dist.get_world_size(self.group) if (self.sync_bn and dist.is_initialized()) else 1
+        """Number of ranks BatchNorm statistics are reduced over (1 = local BN).  With
+        EESEG_FORCE_ALLREDUCE=1 a 1-rank group still issues the collectives (rehearsal on one GPU)."""
+        if not (self.sync_bn and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def sync_active(self):
+        import os
+        return self.sync_bn and dist.is_initialized() and (
+            dist.get_world_size(self.group) > 1 or os.environ.get("EESEG_FORCE_ALLREDUCE") == "1")
 
     def next_seed(self):
         self._drop_calls += 1
@@ -229,7 +238,7 @@ def _geom(conv):
 
 
 def _allreduce(cfg, t):
-    if cfg.world() > 1:
+    if cfg.sync_active():
         dist.all_reduce(t, group=cfg.group)
     return t
 
@@ -246,7 +255,7 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
         c, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
     sums = K.reduce_partials(part)
     count = c.numel() // c.shape[-1]
-    if cfg.world() > 1:
+    if cfg.sync_active():
         _allreduce(cfg, sums)
         count *= cfg.world()
     mom = bn.momentum if bn.momentum is not None else 0.1
@@ -269,7 +278,7 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     else:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
-    if cfg.world() > 1:
+    if cfg.sync_active():
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
         sums = sums.clone() if pair is not None else sums

@@ -32,7 +32,9 @@ class _FusedCE(torch.autograd.Function):
         for e, lr in enumerate(lrs):
             K.upsample_ce_fwd(lr, C, target, H, W, ignore_index, accum[e])
         if mean:
-            if sync and dist.is_initialized() and dist.get_world_size() > 1:
+            import os
+            if sync and dist.is_initialized() and (dist.get_world_size() > 1 or
+                                                   os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"):
                 # global valid-pixel count so that the DP average of the per-rank losses is
                 # the single-device loss of the whole batch
                 cnt = accum[:, 1].clone()
