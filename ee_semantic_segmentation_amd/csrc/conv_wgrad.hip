@@ -81,11 +81,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ci_ok[i] ? basex + i * (TPR * 16) : EESEG_OOB), 0, 0);
         }
     };
-    auto advance = [&]() {
-        pm += KP;
-        pw += KP;
+    auto advance = [&](int steps) {
+        pm += steps * KP;
+        pw += steps * KP;
         while (pw >= p.Wout) { pw -= p.Wout; ph += 1; }
         while (ph >= p.Hout) { ph -= p.Hout; pn += 1; }
+    };
+    // Block-uniform: does K step `kt` contain a pixel row whose tap-shifted source row is inside the
+    // image?  For the atrous convs (|dh| = 12/24/36 on 65 rows) up to 55 % of the steps of the off-centre
+    // tap rows multiply only zero padding and are skipped.
+    auto step_valid = [&](int kt) {
+        const int m_first = ps + kt * KP;
+        const int m_last = min(pe, m_first + KP) - 1;
+        const int r_first = m_first / p.Wout, r_last = m_last / p.Wout;     // global output-row indices
+        for (int rr = r_first; rr <= r_last; ++rr) {
+            const int hi = (rr % p.Hout) * p.stride + dh;
+            if ((unsigned)hi < (unsigned)p.Hin) return true;
+        }
+        return false;
+    };
+    auto next_valid = [&](int kt) {
+        while (kt < nk && !step_valid(kt)) ++kt;
+        return kt;
     };
     auto store_tile = [&](int buf) {
         const int sw = (lrow & 3) << 6;
@@ -106,16 +123,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int wr = wave >> 1, wcI = wave & 1;     // cout half, cin half
-    if (nk > 0) {
+    int kt = next_valid(0);
+    const bool any = kt < nk;
+    if (any) {
+        advance(kt);
         load_tile();
         store_tile(0);
     }
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool has_next = kt + 1 < nk;
+    while (kt < nk) {
+        const int nx = next_valid(kt + 1);
+        const bool has_next = nx < nk;
         if (has_next) {
-            advance();
+            advance(nx - kt);
             load_tile();
         }
         const char* a = sDY + cur * TILE;
@@ -180,10 +201,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
         if (has_next) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+        kt = nx;
     }
 
     // ---- epilogue: fp32 atomics into dW[co][tap][ci] ---------------------------
-    if (nk == 0) return;
+    if (!any) return;
     const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
