@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ee_semantic_segmentation_amd import kernels as K
 from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
-H, W, C = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 2048), 19
-H, W = H if isinstance(H, int) else H[0], W
+H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 2048)
+C = 19
 torch.manual_seed(0)
 net = branchyDeepv3(None, "deeplabv3_resnet101", 3, 1024, count_branches=False, num_classes=C,
                     compute_dtype=torch.bfloat16).cuda().eval()
