@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
     ap.add_argument("--conv-narrow-max", type=int, default=None)
+    ap.add_argument("--conv-auto-narrow", type=int, default=None)
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="run weight-gradient kernels on a side stream (+1%%; per-kernel timings then overlap)")
     args = ap.parse_args()
@@ -128,6 +129,8 @@ def main():
         _eelib().eeseg_set_option(1, args.conv_pipe)
     if args.ew_grid_cap is not None:
         _eelib().eeseg_set_ew_grid_cap(args.ew_grid_cap)
+    if args.conv_auto_narrow is not None:
+        _eelib().eeseg_set_option(4, args.conv_auto_narrow)
     if args.conv_narrow_max is not None:
         _eelib().eeseg_set_option(3, args.conv_narrow_max)
     if args.wgrad_blocks is not None:

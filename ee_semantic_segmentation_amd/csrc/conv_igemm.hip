@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+int g_conv_auto_narrow = 1;
 int g_conv_narrow_max = 64;   // layers with Cout <= this use the 128x64 tile (EESEG_OPT_CONV_NARROW_MAX)
 int g_conv_linear = 0;   // eeseg_set_option(EESEG_OPT_CONV_TAP_INNER, 0|1)
 int g_conv_pipe = 0;     // LDS-DMA staging (A/B on MI355X: +3.5 % end to end over the 2-deep register pipeline)     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
@@ -478,6 +479,10 @@ int launch(const ConvP& p, hipStream_t st) {
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 2)) {
         g_conv_pipe = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_AUTO_NARROW && (value == 0 || value == 1)) {
+        g_conv_auto_narrow = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_CONV_NARROW_MAX && value >= 64 && value <= 4096) {
@@ -535,7 +540,10 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;
-    const bool narrow = a->Cout <= g_conv_narrow_max;
+    // 128x64 tiles for thin outputs, and whenever the 128x128 grid would fill less than ~85 % of the
+    // 512 resident block slots (small batches: M = 4*65*65 gives only 133 pixel tiles)
+    const long long wide_blocks = ((M + BM - 1) / BM) * ((a->Cout + 127) / 128);
+    const bool narrow = a->Cout <= g_conv_narrow_max || (g_conv_auto_narrow && wide_blocks < 448 && a->Cout > 64);
     p.n_tiles = narrow ? (a->Cout + 63) / 64 : (a->Cout + 127) / 128;
     if (a->dtype == EESEG_BF16) return narrow ? launch<bf16_t, 64>(p, st) : launch<bf16_t, 128>(p, st);
     return narrow ? launch<float, 64>(p, st) : launch<float, 128>(p, st);
