@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
-int g_conv_auto_narrow = 1;
+int g_conv_auto_narrow = 0;   // measured neutral at B=4 (that regime is bound by per-kernel fixed costs), off by default
 int g_conv_narrow_max = 64;   // layers with Cout <= this use the 128x64 tile (EESEG_OPT_CONV_NARROW_MAX)
 int g_conv_linear = 0;   // eeseg_set_option(EESEG_OPT_CONV_TAP_INNER, 0|1)
 int g_conv_pipe = 0;     // LDS-DMA staging (A/B on MI355X: +3.5 % end to end over the 2-deep register pipeline)     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)

@@ -38,7 +38,7 @@ int eeseg_version(void);
 /* tuning switches (process wide).  EESEG_OPT_CONV_PIPE: global-load prefetch depth
  * of the implicit-GEMM conv kernel: 0 (default) = tiles staged by LDS-DMA (buffer_load ... lds, no staging
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers. */
-enum { EESEG_OPT_CONV_AUTO_NARROW = 4 /* 1 (default): 128x64 tiles when the 128x128 grid underfills the chip */,
+enum { EESEG_OPT_CONV_AUTO_NARROW = 4 /* 1: 128x64 tiles when the 128x128 grid underfills the chip (default 0) */,
        EESEG_OPT_CONV_NARROW_MAX = 3 /* layers with Cout <= value use the 128x64 tile (default 64) */,
        EESEG_OPT_CONV_PIPE = 1, EESEG_OPT_CONV_TAP_INNER = 2 /* K order: 0 = taps outer (default), 1 = taps inner (fewer L2 misses,
                                   measured 3% slower end to end on MI355X: the Infinity Cache absorbs the re-reads) */ };
