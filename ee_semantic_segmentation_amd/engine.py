@@ -253,13 +253,15 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
         wf, _ = packed(conv, x.dtype)
         s, p, d = _geom(conv)
         c, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
-    sums = K.reduce_partials(part)
     count = c.numel() // c.shape[-1]
+    mom = bn.momentum if bn.momentum is not None else 0.1
     if cfg.sync_active():
+        sums = K.reduce_partials(part)
         _allreduce(cfg, sums)
         count *= cfg.world()
-    mom = bn.momentum if bn.momentum is not None else 0.1
-    mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+        mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+    else:       # local BatchNorm: partial reduction and finalize fused in one launch
+        mi, ss = K.bn_reduce_finalize(part, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
     bn._pending_batches += 1
     y = K.bn_apply(c, ss, residual=residual, relu=relu, out=out)
     # backward recomputes the ReLU mask from c*scale+shift when there is no residual input

@@ -264,6 +264,17 @@ def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_v
     return mean_invstd, scale_shift
 
 
+def bn_reduce_finalize(partials, count, gamma, beta, eps, momentum, running_mean, running_var):
+    """partials [tiles,2,C] -> (mean_invstd [2,C], scale_shift [2,C]) in one launch."""
+    tiles, _, Cc = partials.shape
+    mean_invstd = torch.empty((2, Cc), dtype=torch.float32, device=partials.device)
+    scale_shift = torch.empty((2, Cc), dtype=torch.float32, device=partials.device)
+    check(lib().eeseg_bn_reduce_finalize(_p(partials), tiles, float(count), _p(gamma), _p(beta), eps, momentum,
+                                         _p(running_mean), _p(running_var), _p(mean_invstd), _p(scale_shift), Cc,
+                                         _stream()), "eeseg_bn_reduce_finalize")
+    return mean_invstd, scale_shift
+
+
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
     Cc = running_mean.numel()
     ss = torch.empty((2, Cc), dtype=torch.float32, device=running_mean.device)

@@ -121,6 +121,10 @@ int eeseg_bn_reduce_partials(const float* partials, int tiles, int KC, float* su
 int eeseg_bn_finalize(const float* sums /*[2][C]*/, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* running_mean, float* running_var,
                       float* mean_invstd, float* scale_shift, int C, void* stream);
+/* reduce + finalize in one launch (local BatchNorm: partials[tiles][2][C] straight from the conv epilogue) */
+int eeseg_bn_reduce_finalize(const float* partials, int tiles, double count, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, float* mean_invstd,
+                             float* scale_shift, int C, void* stream);
 /* eval mode: scale/shift from running stats */
 int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                               const float* running_var, float eps, float* scale_shift, int C, void* stream);

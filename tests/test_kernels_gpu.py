@@ -433,3 +433,18 @@ def test_conv_alternate_pipelines(pipe, dtype):
             test_conv_fwd_dgrad_wgrad(case, dtype)
     finally:
         lib().eeseg_set_option(1, 2)
+
+
+def test_bn_reduce_finalize_fused_equals_two_step():
+    g = torch.Generator().manual_seed(21)
+    for tiles, Cc in [(1, 64), (37, 256), (529, 2048), (8257, 64)]:
+        part = torch.rand(tiles, 2, Cc, generator=g).to(DEV) * 100
+        part[:, 1] += 50
+        gamma, beta = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV)
+        rm1, rv1 = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        cnt = tiles * 128
+        mi1, ss1 = K.bn_finalize(K.reduce_partials(part), cnt, gamma, beta, 1e-5, 0.1, rm1, rv1)
+        mi2, ss2 = K.bn_reduce_finalize(part, cnt, gamma, beta, 1e-5, 0.1, rm2, rv2)
+        for a, b, what in [(mi1, mi2, "mean/invstd"), (ss1, ss2, "scale/shift"), (rm1, rm2, "rm"), (rv1, rv2, "rv")]:
+            close(b, a, 2e-6, f"{what} tiles={tiles} C={Cc}")
