@@ -24,7 +24,8 @@ class ConvArgs(C.Structure):
                 ("stats", C.c_void_p)] + \
                [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
                                        "smul", "off_h", "off_w", "tstep_h", "tstep_w", "sdiv",
-                                       "ldy", "ldres", "relu", "dtype")]
+                                       "ldy", "ldres", "relu", "dtype")] + \
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
 
 
 class WgradArgs(C.Structure):
@@ -40,10 +41,12 @@ SIGNATURES = {
     "eeseg_last_error": (C.c_char_p, []),
     "eeseg_version": (_i, []),
     "eeseg_set_option": (_i, [_i, _i]),
+    "eeseg_get_option": (_i, [_i]),
     "eeseg_set_ew_grid_cap": (_i, [_i]),
     "eeseg_set_wgrad_target_blocks": (_i, [_i]),
     "eeseg_conv_stats_tiles": (_i, [_i, _i, _i]),
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
+    "eeseg_conv_workspace": (_i64, []),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),
     "eeseg_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_pack_weight_multi": (_i, [_vp, _i, _i, _vp]),

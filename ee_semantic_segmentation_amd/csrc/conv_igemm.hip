@@ -27,6 +27,8 @@ struct ConvP {
     uint32_t xbytes, wbytes;
     int vec_ok;   // 1: 16-byte row stores allowed (alignment / Cout multiple)
     int tap_inner;   // LINEAR kernels: K order (0 = taps outer / channels inner, 1 = taps inner)
+    int tile_begin, ksplit;   // 256x256 kernel: first tile of this launch, K ranges per tile
+    float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
 };
 
 template <typename T> struct Mma;
@@ -452,16 +454,512 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 pixels x 256 couts, 8 waves (4 along cout x 2 along pixels, 64 x 128 outputs per wave), one
+// block per CU.  bf16, linear addressing, taps outer.  The K loop keeps LDS-DMA loads in flight
+// ACROSS barriers: two K tiles of LDS (2 x 64 KiB), each split into four 16-KiB half tiles
+// (pixel halves XA/XB, cout halves W0/W1, rows permuted so that every wave reads its own quadrant
+// from each half); a K tile is consumed in four phases (one 32x64 quadrant x K=64 each = 8 MFMAs
+// per wave) and a half tile is refilled with the data of K tile t+2 in the phase after its last
+// reader, so every load has >= 6 phases to land.  Waits are counted (s_waitcnt vmcnt(N), never 0
+// inside the loop) and placed one phase ahead of the first read of the buffer they retire;
+// barriers are raw s_barrier (no fence: __syncthreads() would drain the DMA queue).
+//
+// One 256x256 tile per CU quantizes badly (16 x 65 x 65 pixels = 265 tiles on 256 CUs), so the
+// tiles beyond the last full round of 256 are split along K over the idle CUs:
+//   MODE 0: whole tile, fused epilogue;   MODE 1: one K range of a tile -> fp32 slab (register
+//   layout, 1-KiB coalesced stores), summed by conv_big_fixup_kernel in a fixed order with the
+//   same fused epilogue.
+constexpr int BIGT = 256;
+constexpr int HT = 128 * ROWB;                               // half tile: 128 rows x 128 B
+constexpr int BIG_SROW = BIGT * 2 + 16;                      // staged output row (bf16) + pad
+constexpr int BIG_EPI = BIGT * BIG_SROW + 8 * 2 * BIGT * 4;  // staging + [8 waves][2][256] stats
+constexpr int BIG_LDS = (BIG_EPI > 8 * HT ? BIG_EPI : 8 * HT) + 16;
+constexpr int SLAB_FLOATS = BIGT * BIGT;
+
+#define BIG_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define BIG_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
+    typedef bf16_t T;
+    typedef Mma<T>::Frag Frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsplit = (MODE == 1) ? p.ksplit : 1;
+    const int tile_local = (MODE == 1) ? unit / nsplit : unit;
+    const int split = (MODE == 1) ? unit - tile_local * nsplit : 0;
+    const int tile = p.tile_begin + tile_local;
+    const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
+    const int m0 = mt * BIGT, n0 = nt * BIGT;
+    const int wc = wave & 3, wp = wave >> 2;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    {
+        unsigned* sMask = reinterpret_cast<unsigned*>(smem + BIG_LDS - 16);
+        const int taps = p.R * p.S;
+        // DMA role: one wave-instruction = 8 rows x 128 B; per half tile a thread fetches rows rr and rr+64
+        const int rr = wave * 8 + (lane >> 3);
+        const int gchunk = (lane & 7) ^ ((rr >> 1) & 7);    // XOR swizzle on the SOURCE chunk (LDS image is lane-linear)
+        // pixel rows [h][q] -> block pixel q*128 + h*64 + rr;  cout rows [i][q] -> ((rr>>5) + 2q)*64 + i*32 + (rr&31)
+        int hb[4], wb[4], nb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + (k & 1) * 128 + (k >> 1) * 64 + rr;
+            if (m < p.M) {
+                const int n = m / p.HWout;
+                const int rem = m - n * p.HWout;
+                const int ho = rem / p.Wout;
+                const int wo = rem - ho * p.Wout;
+                hb[k] = ho * p.smul + p.off_h;
+                wb[k] = wo * p.smul + p.off_w;
+                nb[k] = n * p.Hin * p.Win;
+            } else {
+                hb[k] = -(1 << 28); wb[k] = -(1 << 28); nb[k] = 0;
+            }
+        }
+        if (tid == 0) *sMask = 0u;
+        __syncthreads();
+        unsigned vmask[4] = {0u, 0u, 0u, 0u};
+        {
+            for (int t = 0; t < taps; ++t) {
+                const int r = t / p.S, s = t - r * p.S;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int hi = hb[k] + r * p.tstep_h, wi = wb[k] + s * p.tstep_w;
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) vmask[k] |= 1u << t;
+                }
+            }
+            unsigned mine = vmask[0] | vmask[1] | vmask[2] | vmask[3];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
+            if (lane == 0 && mine) atomicOr(sMask, mine);
+        }
+        __syncthreads();
+        const unsigned tapmask = *sMask;
+        const int kc_steps = p.Cin / 64;
+        const int nk_all = __popc(tapmask) * kc_steps;
+        const int k_begin = (MODE == 1) ? (int)((long long)split * nk_all / nsplit) : 0;
+        const int k_end = (MODE == 1) ? (int)((long long)(split + 1) * nk_all / nsplit) : nk_all;
+        const int nk = k_end - k_begin;
+        __syncthreads();                   // sMask lies inside the epilogue staging area
+
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
+
+        int baseA[4];
+        uint32_t voffA[4], voffW[4], voffWl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            baseA[k] = ((nb[k] + hb[k] * p.Win + wb[k]) * p.Cin) * 2 + gchunk * 16;
+            const int co = n0 + ((rr >> 5) + 2 * (k & 1)) * 64 + (k >> 1) * 32 + (rr & 31);
+            voffW[k] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * 2 + gchunk * 16) : EESEG_OOB;
+            voffA[k] = EESEG_OOB; voffWl[k] = EESEG_OOB;
+        }
+        // block-uniform iterator over the K tiles (taps outer, channels inner), starting at K tile k_begin
+        unsigned rest = tapmask;
+        for (int i = k_begin / kc_steps; i > 0; --i) rest &= rest - 1;
+        int ci = k_begin % kc_steps - 1, cur_tap = 0, dtap = 0, soffA = 0, soffW = 0, remain = nk;
+        bool live = true, upd = true;
+        auto pop_tap = [&]() {
+            cur_tap = rest ? __ffs(rest) - 1 : 0;
+            rest &= rest - 1;
+            const int r = cur_tap / p.S, s = cur_tap - r * p.S;
+            dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * 2;
+            upd = true;
+        };
+        if (ci >= 0) pop_tap(); else ci = kc_steps - 1;      // mid-tap start: that tap is current; else the first call pops
+        auto next_tile = [&]() {
+            if (++ci >= kc_steps) { ci = 0; pop_tap(); }
+            if (remain-- == 0) { live = false; upd = true; }  // past the last tile: out-of-range (zero, no traffic) loads
+            if (upd) {
+                upd = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    voffA[k] = (live && ((vmask[k] >> cur_tap) & 1u)) ? (uint32_t)(baseA[k] + dtap) : EESEG_OOB;
+                    voffWl[k] = live ? voffW[k] : EESEG_OOB;
+                }
+            }
+            soffA = ci * ROWB;
+            soffW = (cur_tap * p.Cin) * 2 + ci * ROWB;
+        };
+        const int w8 = __builtin_amdgcn_readfirstlane(wave) * 8;
+        auto dmaX = [&](int s, int h) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (s * 4 + h) * HT + (q * 64 + w8) * ROWB), 16,
+                                                         (int)voffA[h * 2 + q], soffA, 0, 0);
+        };
+        auto dmaW = [&](int s, int i) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + (s * 4 + 2 + i) * HT + (q * 64 + w8) * ROWB), 16,
+                                                         (int)voffWl[i * 2 + q], soffW, 0, 0);
+        };
+        auto rdW = [&](const char* sb, int i, Frag (&f)[4]) {
+            const char* a = sb + (2 + i) * HT + (wc * 32 + fr) * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const Frag*>(a + (((ks * 2 + fh) ^ fsw) << 4));
+        };
+        auto rdX = [&](const char* sb, int h, int jj, Frag (&f)[4]) {
+            const char* a = sb + h * HT + (wp * 64 + jj * 32 + fr) * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const Frag*>(a + (((ks * 2 + fh) ^ fsw) << 4));
+        };
+        auto mma4 = [&](const Frag (&a)[4], const Frag (&b0)[4], const Frag (&b1)[4], f32x16& c0, f32x16& c1) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                Mma<T>::run(a[ks], b0[ks], c0);
+                Mma<T>::run(a[ks], b1[ks], c1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        // Two wave groups (waves 0-3 / 4-7 = one wave per SIMD each) run the phase sequence
+        //   [refill DMAs | LDS reads | counted wait] barrier [8 MFMAs] barrier
+        // half a phase apart (group 1 takes one extra barrier up front, group 0 one at the end), so between any
+        // two barriers one group reads LDS while the other owns the MFMA pipes.  Consequences for the waits:
+        //   * a half tile last read in phase P is refilled at the start of phase P+2 (by then the lagging
+        //     group has consumed its reads);
+        //   * the wait that retires the loads of phase Q sits in phase Q-1 after the reads, before the barrier.
+        // Issue order per iteration: phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2).
+        next_tile(); dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);      // K tile 0
+        next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);                  // K tile 1 without XB
+        BIG_WAIT(6);
+        BIG_BARRIER();
+        const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
+        if (lagging) BIG_BARRIER();
+        for (int t = 0; t < nk; ++t) {
+            const int s = t & 1;
+            const char* sb = smem + s * 4 * HT;
+            Frag w0[4], w1[4], xa0[4], xa1[4], xb0[4], xb1[4];
+            // phase 1: quadrant (W0, XA); refill XB of the other stage (last read in phase 3 of the previous tile)
+            dmaX(s ^ 1, 1);
+            rdW(sb, 0, w0); rdX(sb, 0, 0, xa0); rdX(sb, 0, 1, xa1);
+            BIG_WAIT(10);                  // W1(t) landed
+            BIG_BARRIER();
+            mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+            BIG_BARRIER();
+            // phase 2: quadrant (W1, XA)
+            rdW(sb, 1, w1);
+            BIG_WAIT(8);                   // XB(t) landed
+            BIG_BARRIER();
+            mma4(w1, xa0, xa1, acc[1][0], acc[1][1]);
+            BIG_BARRIER();
+            // phase 3: quadrant (W1, XB); refill XA, W0 (last read in phase 1) with K tile t+2
+            next_tile();
+            dmaX(s, 0); dmaW(s, 0);
+            rdX(sb, 1, 0, xb0); rdX(sb, 1, 1, xb1);
+            BIG_BARRIER();
+            mma4(w1, xb0, xb1, acc[1][2], acc[1][3]);
+            BIG_BARRIER();
+            // phase 4: quadrant (W0, XB) from registers; refill W1 (last read in phase 2)
+            dmaW(s, 1);
+            BIG_WAIT(10);                  // XA(t+1), W0(t+1) landed
+            BIG_BARRIER();
+            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+            BIG_BARRIER();
+        }
+        if (!lagging) BIG_BARRIER();
+        BIG_WAIT(0);                       // trailing out-of-range DMAs still write (zeros) into LDS
+        BIG_BARRIER();
+    }
+
+    if constexpr (MODE == 1) {             // partial sums of this K range, register layout: 1 KiB per wave store
+        if (p.stats && split == 0) {       // the fix-up kernel adds its 32-pixel slices into this tile's two stat rows
+            const int which = tid >> 8, col = tid & 255;
+            p.stats[((size_t)(2 * mt) * 2 + which) * p.Cout + n0 + col] = 0.f;
+            if (2 * mt + 1 < p.m_tiles) p.stats[((size_t)(2 * mt + 1) * 2 + which) * p.Cout + n0 + col] = 0.f;
+        }
+        float* ws = p.slabs + ((size_t)tile_local * nsplit + split) * SLAB_FLOATS + (wave * 32) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(ws + ((i * 4 + j) * 4 + g) * 256) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        return;
+    }
+
+    // ---- epilogue 1: acc -> (scale, shift) -> LDS staging [pixel][cout] --------
+    char* stage = smem;
+    float* sRed = reinterpret_cast<float*>(smem + BIGT * BIG_SROW);   // [8 waves][2][256]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wc * 64 + i * 32 + 8 * g + 4 * fh;
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = n0 + cl + e;
+                if (co < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[co];
+                    if (p.shift) sh[e] = p.shift[co];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int px = wp * 128 + j * 32 + fr;
+                T v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][j][4 * g + e] * sc[e] + sh[e]);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<T*>(stage + px * BIG_SROW) + cl) = bf16x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: row-major read back, residual/ReLU, stats, coalesced 16-byte stores ----
+    const int c = tid & 31, r0 = tid >> 5;
+    const int cg = n0 + c * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* yout = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const bool full = p.vec_ok && (cg + 8 <= p.Cout);
+    for (int row = r0; row < BIGT; row += 16) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        union { i32x4 q; T e[8]; } u;
+        u.q = *reinterpret_cast<const i32x4*>(stage + row * BIG_SROW + c * 16);
+        T* v = u.e;
+        if (res != nullptr) {
+            if (full) {
+                union { i32x4 q; T e[8]; } ur;
+                ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = to_f32(v[e]);
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+        if (full) {
+            *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 32);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sRed[(wave * 2 + 0) * BIGT + lane * 8 + e] = s1[e];
+                sRed[(wave * 2 + 1) * BIGT + lane * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        const int which = tid >> 8, col = tid & 255;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += sRed[(w * 2 + which) * BIGT + col];
+        if (n0 + col < p.Cout) {
+            // the partial-sum buffer has one row pair per 128 pixels (eeseg_conv_stats_tiles): this tile owns two
+            p.stats[((size_t)(2 * mt) * 2 + which) * p.Cout + n0 + col] = t;
+            if (2 * mt + 1 < p.m_tiles) p.stats[((size_t)(2 * mt + 1) * 2 + which) * p.Cout + n0 + col] = 0.f;
+        }
+    }
+}
+
+// Fix-up of the K-split tiles: one block per 32-pixel slice of a tile (8 per tile, 4 waves = the 4 cout
+// groups): sums the slabs in a fixed order, then the fused epilogue; BN partial sums of the 4 slices that
+// share a 128-pixel stat row are combined with fp32 atomics (rows zeroed by the MODE 1 kernel).
+__global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
+    typedef bf16_t T;
+    constexpr int SL = 32;                                   // pixels per slice
+    __shared__ __attribute__((aligned(16))) char smem[SL * BIG_SROW + 4 * 2 * BIGT * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int tile_local = blockIdx.x >> 3, slice = blockIdx.x & 7;
+    const int wp = slice >> 2, j = slice & 3;
+    const int tile = p.tile_begin + tile_local;
+    const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
+    const int m0 = mt * BIGT + wp * 128 + j * SL, n0 = nt * BIGT;
+    const int fr = lane & 31, fh = lane >> 5;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ws = p.slabs + (size_t)tile_local * p.ksplit * SLAB_FLOATS + ((wp * 4 + wc) * 32 + j * 4) * 256 + lane * 4;
+    for (int s = 0; s < p.ksplit; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[i][g] += *reinterpret_cast<const f32x4*>(ws + (size_t)s * SLAB_FLOATS + (i * 16 + g) * 256);
+    }
+    char* stage = smem;
+    float* sRed = reinterpret_cast<float*>(smem + SL * BIG_SROW);   // [4 waves][2][256]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wc * 64 + i * 32 + 8 * g + 4 * fh;
+            T v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = n0 + cl + e;
+                const float sc = (p.scale && co < p.Cout) ? p.scale[co] : 1.f;
+                const float sh = (p.shift && co < p.Cout) ? p.shift[co] : 0.f;
+                v[e] = from_f32<T>(acc[i][g][e] * sc + sh);
+            }
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<T*>(stage + fr * BIG_SROW) + cl) = bf16x4{v[0], v[1], v[2], v[3]};
+        }
+    __syncthreads();
+    const int c = tid & 31, r0 = tid >> 5;
+    const int cg = n0 + c * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* yout = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const bool full = p.vec_ok && (cg + 8 <= p.Cout);
+    for (int row = r0; row < SL; row += 8) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        union { i32x4 q; T e[8]; } u;
+        u.q = *reinterpret_cast<const i32x4*>(stage + row * BIG_SROW + c * 16);
+        T* v = u.e;
+        if (res != nullptr) {
+            if (full) {
+                union { i32x4 q; T e[8]; } ur;
+                ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = to_f32(v[e]);
+                s1[e] += f;
+                s2[e] += f * f;
+            }
+        }
+        if (full) {
+            *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 32);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sRed[(wc * 2 + 0) * BIGT + lane * 8 + e] = s1[e];
+                sRed[(wc * 2 + 1) * BIGT + lane * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        const int col = tid;                                  // 256 threads = 256 couts, both sums
+        const int srow = 2 * mt + wp;
+        if (n0 + col < p.Cout && srow < p.m_tiles) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const float t = sRed[(0 * 2 + which) * BIGT + col] + sRed[(1 * 2 + which) * BIGT + col] +
+                                sRed[(2 * 2 + which) * BIGT + col] + sRed[(3 * 2 + which) * BIGT + col];
+                atomicAdd(&p.stats[((size_t)srow * 2 + which) * p.Cout + n0 + col], t);
+            }
+        }
+    }
+}
+
+int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
+
+// launch plan for the 256x256 kernel: full rounds of 256 tiles, then the remainder split along K
+int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long workspace_bytes) {
+    const int tiles = (int)((M + BIGT - 1) / BIGT) * p.n_tiles;
+    const int rounds = tiles / 256, rem = tiles % 256;
+    const int nk_max = p.R * p.S * (p.Cin / 64);
+    int ksplit = 1;
+    if (rem > 0 && rem < g_conv_big_tail_min) {
+        ksplit = 256 / rem;
+        if (ksplit > nk_max / 4) ksplit = nk_max / 4;            // at least 4 K tiles per range (pipeline fill)
+        const long long fit = workspace ? workspace_bytes / ((long long)rem * SLAB_FLOATS * 4) : 0;
+        if (ksplit > fit) ksplit = (int)fit;
+    }
+    if (ksplit < 2) {
+        p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr;
+        hipLaunchKernelGGL(conv_big_kernel<0>, dim3(tiles), dim3(512), 0, st, p);
+        EESEG_LAUNCH_CHECK();
+        return EESEG_OK;
+    }
+    p.slabs = reinterpret_cast<float*>(workspace);
+    p.ksplit = ksplit;
+    if (rounds > 0) {
+        p.tile_begin = 0;
+        hipLaunchKernelGGL(conv_big_kernel<0>, dim3(rounds * 256), dim3(512), 0, st, p);
+    }
+    p.tile_begin = rounds * 256;
+    hipLaunchKernelGGL(conv_big_kernel<1>, dim3(rem * ksplit), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(conv_big_fixup_kernel, dim3(rem * 8), dim3(256), 0, st, p);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
 int g_conv_auto_narrow = 0;   // measured neutral at B=4 (that regime is bound by per-kernel fixed costs), off by default
 int g_conv_narrow_max = 64;   // layers with Cout <= this use the 128x64 tile (EESEG_OPT_CONV_NARROW_MAX)
 int g_conv_linear = 0;   // eeseg_set_option(EESEG_OPT_CONV_TAP_INNER, 0|1)
-int g_conv_pipe = 0;     // LDS-DMA staging (A/B on MI355X: +3.5 % end to end over the 2-deep register pipeline)     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 1|2)
+int g_conv_pipe = 3;     // eeseg_set_option(EESEG_OPT_CONV_PIPE, 0..3): 3 = 256x256 kernel where eligible, LDS-DMA 128x128 elsewhere
+                         // (A/B on MI355X, R50 layer set at B=16: conv fwd+dgrad 21.5 -> 17.1 ms per step)
 
 template <typename T, int BN>
 int launch(const ConvP& p, hipStream_t st) {
     const int grid = p.m_tiles * p.n_tiles;
     const bool lin = (p.sdiv == 1);            // linear addressing whenever the source coordinate is linear in the tap
-    if (lin && g_conv_pipe == 0) {
+    if (lin && (g_conv_pipe == 0 || g_conv_pipe == 3)) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 0, true>), dim3(grid), dim3(256), 0, st, p);
     } else if (lin && g_conv_pipe == 2) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, BN, 2, true>), dim3(grid), dim3(256), 0, st, p);
@@ -477,7 +975,7 @@ int launch(const ConvP& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int eeseg_set_option(int key, int value) {
-    if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 2)) {
+    if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
         g_conv_pipe = value;
         return EESEG_OK;
     }
@@ -489,6 +987,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_narrow_max = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_TAIL_MIN && value >= 0 && value <= 256) {
+        g_conv_big_tail_min = value;
+        return EESEG_OK;
+    }
     if (key == EESEG_OPT_CONV_TAP_INNER && (value == 0 || value == 1)) {
         g_conv_linear = value;
         return EESEG_OK;
@@ -497,9 +999,25 @@ extern "C" int eeseg_set_option(int key, int value) {
     return EESEG_ERR_ARG;
 }
 
+extern "C" int eeseg_get_option(int key) {
+    switch (key) {
+        case EESEG_OPT_CONV_PIPE: return g_conv_pipe;
+        case EESEG_OPT_CONV_TAP_INNER: return g_conv_linear;
+        case EESEG_OPT_CONV_NARROW_MAX: return g_conv_narrow_max;
+        case EESEG_OPT_CONV_AUTO_NARROW: return g_conv_auto_narrow;
+        case EESEG_OPT_CONV_TAIL_MIN: return g_conv_big_tail_min;
+    }
+    eeseg_set_error("get_option: unknown key %d", key);
+    return EESEG_ERR_ARG;
+}
+
 extern "C" int eeseg_conv_stats_tiles(int N, int Hout, int Wout) {
     const long long M = (long long)N * Hout * Wout;
     return (int)((M + BM - 1) / BM);
+}
+
+extern "C" int64_t eeseg_conv_workspace(void) {
+    return 256ll * SLAB_FLOATS * 4;      // tiles of the split round x K ranges <= 256 slabs of 256 KiB
 }
 
 extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
@@ -537,9 +1055,14 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
+    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr;
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;
+    if (g_conv_pipe == 3 && a->dtype == EESEG_BF16 && a->sdiv == 1 && a->Cout % BIGT == 0) {
+        p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
+        return launch_big(p, M, st, a->workspace, a->workspace_bytes);
+    }
     // 128x64 tiles for thin outputs, and whenever the 128x128 grid would fill less than ~85 % of the
     // 512 resident block slots (small batches: M = 4*65*65 gives only 133 pixel tiles)
     const long long wide_blocks = ((M + BM - 1) / BM) * ((a->Cout + 127) / 128);

@@ -97,6 +97,17 @@ def workspace(nbytes, device):
     return t
 
 
+def _conv_ws(device):
+    """Fixed scratch of the conv kernel (split-K slabs of a partly filled last round of tiles); allocated once
+    per device so its address is stable under HIP-graph capture."""
+    key = ("conv", str(device))
+    t = _ws.get(key)
+    if t is None:
+        t = torch.empty(int(lib().eeseg_conv_workspace()), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -113,11 +124,16 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, Hin, Win, Cin, Hout, Wout, Cout, R, S
     a.smul, a.off_h, a.off_w, a.tstep_h, a.tstep_w, a.sdiv = smul, off, off, tstep, tstep, sdiv
     a.ldy, a.ldres, a.relu, a.dtype = ldy, ldres, int(relu), _dt(x)
+    ws = _conv_ws(x.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     ev = _prof_begin()
     check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
     if ev is not None:
         px = N * (Hin * Win if sdiv > 1 else Hout * Wout)      # algorithmic MACs (padding taps included)
-        fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
+        if a.dtype == BF16 and sdiv == 1 and Cout % 256 == 0 and lib().eeseg_get_option(1) == 3:
+            fam = "conv_big_kernel<bf16,256x256>"      # one call = full rounds (+ K-split tail + fix-up) launches
+        else:
+            fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
         es = 2 if a.dtype == BF16 else 4       # algorithmic bytes: every operand once
         _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S,
                   float(es) * (N * Hin * Win * Cin + Cout * R * S * Cin + N * Hout * Wout * Cout))

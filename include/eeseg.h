@@ -36,13 +36,17 @@ enum {
 const char* eeseg_last_error(void);
 int eeseg_version(void);
 /* tuning switches (process wide).  EESEG_OPT_CONV_PIPE: global-load prefetch depth
- * of the implicit-GEMM conv kernel: 0 (default) = tiles staged by LDS-DMA (buffer_load ... lds, no staging
- * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers. */
-enum { EESEG_OPT_CONV_AUTO_NARROW = 4 /* 1: 128x64 tiles when the 128x128 grid underfills the chip (default 0) */,
+ * of the implicit-GEMM conv kernel: 0 = tiles staged by LDS-DMA (buffer_load ... lds, no staging
+ * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
+ * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
+ * everything else as 0 (default). */
+enum { EESEG_OPT_CONV_TAIL_MIN = 5 /* 256x256 kernel: a last round with fewer tiles than this is split along K (default 224; 0 = never) */,
+       EESEG_OPT_CONV_AUTO_NARROW = 4 /* 1: 128x64 tiles when the 128x128 grid underfills the chip (default 0) */,
        EESEG_OPT_CONV_NARROW_MAX = 3 /* layers with Cout <= value use the 128x64 tile (default 64) */,
        EESEG_OPT_CONV_PIPE = 1, EESEG_OPT_CONV_TAP_INNER = 2 /* K order: 0 = taps outer (default), 1 = taps inner (fewer L2 misses,
                                   measured 3% slower end to end on MI355X: the Infinity Cache absorbs the re-reads) */ };
 int eeseg_set_option(int key, int value);
+int eeseg_get_option(int key);   /* current value, or a negative error code */
 /* upper bound on the grid of the column-fixed BatchNorm elementwise kernels (tuning) */
 int eeseg_set_ew_grid_cap(int blocks);
 /* split-K sizing of the weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at */
@@ -69,7 +73,10 @@ typedef struct {
     int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
     int smul, off_h, off_w, tstep_h, tstep_w, sdiv;
     int ldy, ldres, relu, dtype;
+    void* workspace;              /* optional scratch (NULL = none): lets the 256x256-tile kernel split the K loop of its */
+    int64_t workspace_bytes;      /* last, partly filled round of tiles over the idle CUs; eeseg_conv_workspace() bytes suffice */
 } eeseg_conv_args;
+int64_t eeseg_conv_workspace(void);
 int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */
 int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream);
 

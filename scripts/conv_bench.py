@@ -62,19 +62,19 @@ for shp, cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][
     fl = 2.0 * y.numel() * Cin * k * k
     from ee_semantic_segmentation_amd._lib import lib
     best = {}
-    for rnd in range(3):                     # interleaved A/B of the two pipelines in one process
-        for pipe in (1, 2):                  # here: 1 = LDS-DMA staging (PIPE 0), 2 = default 2-deep registers
-            lib().eeseg_set_option(1, 0 if pipe == 1 else 2)
+    for rnd in range(3):                     # interleaved A/B of two kernels in one process
+        for pipe in (0, 3):                  # 0 = 128x128 LDS-DMA (default), 3 = 256x256 deep-pipelined where eligible
+            lib().eeseg_set_option(1, pipe)
             t1 = timeit(lambda: K.conv_fwd(x, wf, s, p, d, want_stats=True))
             t2 = timeit(lambda: K.conv_dgrad(gy, wb, (H, W), s, p, d))
             best[pipe] = (min(best.get(pipe, (9, 9))[0], t1), min(best.get(pipe, (9, 9))[1], t2))
-    lib().eeseg_set_option(1, 2)
-    tf, td = best[2]
-    tot["f2"] += best[1][0] * cnt; tot["d2"] += best[1][1] * cnt
+    lib().eeseg_set_option(1, 0)
+    tf, td = best[0]
+    tot["f2"] += best[3][0] * cnt; tot["d2"] += best[3][1] * cnt
     tw = timeit(lambda: K.conv_wgrad(x, gy, k, k, s, p, d))
     tot["f"] += tf * cnt; tot["d"] += td * cnt; tot["w"] += tw * cnt; tot["fl"] += fl * cnt
     print(f"{str(shp):42s} {cnt:3d} {fl/1e9:7.1f} | {tf*1e3:7.3f} {fl/tf/1e12:5.0f} | {td*1e3:8.3f} {fl/td/1e12:5.0f} | "
-          f"{tw*1e3:8.3f} {fl/tw/1e12:5.0f}")
-print(f"LDS-DMA (PIPE=0) totals: fwd {tot['f2']*1e3:.2f} ms dgrad {tot['d2']*1e3:.2f} ms   (PIPE=2 = default below)")
+          f"{tw*1e3:8.3f} {fl/tw/1e12:5.0f} || big: fwd {best[3][0]*1e3:7.3f} {fl/best[3][0]/1e12:5.0f}  dgrad {best[3][1]*1e3:7.3f} {fl/best[3][1]/1e12:5.0f}", flush=True)
+print(f"256x256 kernel (PIPE=3) totals: fwd {tot['f2']*1e3:.2f} ms dgrad {tot['d2']*1e3:.2f} ms   (default PIPE=0 below)")
 print(f"TOTAL per step: fwd {tot['f']*1e3:.2f} ms ({tot['fl']/tot['f']/1e12:.0f} TF)  dgrad {tot['d']*1e3:.2f} ms "
       f"({tot['fl']/tot['d']/1e12:.0f} TF)  wgrad {tot['w']*1e3:.2f} ms ({tot['fl']/tot['w']/1e12:.0f} TF)")

@@ -7,6 +7,11 @@ H, W, Cin, Cout, k, s, p, d, B = [int(v) for v in sys.argv[1:10]]
 mode = sys.argv[10] if len(sys.argv) > 10 else "fwd"
 iters = int(sys.argv[11]) if len(sys.argv) > 11 else 3
 dtype = torch.bfloat16
+if os.environ.get("EESEG_CONV_PIPE"):
+    from ee_semantic_segmentation_amd._lib import lib
+    lib().eeseg_set_option(1, int(os.environ["EESEG_CONV_PIPE"]))
+    if os.environ.get("EESEG_CONV_TAIL_MIN"):
+        lib().eeseg_set_option(5, int(os.environ["EESEG_CONV_TAIL_MIN"]))
 x = torch.randn(B, H, W, Cin, device="cuda").to(dtype)
 wt = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
 wf, wb = K.pack_weight(wt, dtype)

@@ -448,3 +448,51 @@ def test_bn_reduce_finalize_fused_equals_two_step():
         mi2, ss2 = K.bn_reduce_finalize(part, cnt, gamma, beta, 1e-5, 0.1, rm2, rv2)
         for a, b, what in [(mi1, mi2, "mean/invstd"), (ss1, ss2, "scale/shift"), (rm1, rm2, "rm"), (rv1, rv2, "rv")]:
             close(b, a, 2e-6, f"{what} tiles={tiles} C={Cc}")
+
+
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 33, 33, 128, 256, 3, 1, 12, 12),      # atrous: whole taps masked for many pixels, ragged last tile
+    (1, 16, 16, 64, 256, 1, 1, 0, 1),         # exactly one 256-pixel tile, one K tile
+    (3, 19, 23, 256, 512, 3, 1, 1, 1),        # two cout tiles, M not a multiple of 256 (+ dgrad)
+    (1, 9, 9, 64, 256, 3, 1, 2, 2),           # fewer pixels than one tile
+    (2, 31, 31, 256, 256, 3, 2, 1, 1),        # strided forward (smul = 2)
+])
+def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
+    """EESEG_OPT_CONV_PIPE=3 (256x256 tile, loads in flight across barriers) accumulates in the same K order
+    with the same MFMA as the default kernel: with the split-K tail off (EESEG_OPT_CONV_TAIL_MIN=0) outputs are
+    bit identical; with it on (default) the tail tiles sum K ranges in another order -> one bf16 ulp."""
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W, Cin, Cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(DEV)
+    wf, wb = K.pack_weight(wt, torch.bfloat16)
+    sc = torch.rand(Cout, generator=torch.Generator().manual_seed(1)).to(DEV) + 0.5
+    sh = torch.randn(Cout, generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = None
+    outs = {}
+    try:
+        for name, pipe, tail in (("ref", 0, 224), ("big", 3, 0), ("split", 3, 224)):
+            lib().eeseg_set_option(1, pipe)
+            lib().eeseg_set_option(5, tail)
+            y, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
+            if res is None:
+                res = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
+            y2, _ = K.conv_fwd(x, wf, s, p, d, scale=sc, shift=sh, residual=res, relu=True)
+            dx = K.conv_dgrad(y, wb, (H, W), s, p, d) if s == 1 and Cin % 256 == 0 else None
+            torch.cuda.synchronize()
+            outs[name] = (y, K.reduce_partials(part), y2, dx)
+    finally:
+        lib().eeseg_set_option(1, 0)
+        lib().eeseg_set_option(5, 224)
+    ref = outs["ref"]
+    assert torch.equal(ref[0], outs["big"][0])
+    assert torch.equal(ref[2], outs["big"][2])
+    close(outs["big"][1], ref[1], 1e-5, "BN partial sums")
+    if ref[3] is not None:
+        assert torch.equal(ref[3], outs["big"][3])
+    for i, what in ((0, "y"), (2, "fused epilogue"), (3, "dgrad")):
+        if ref[i] is not None:
+            close(outs["split"][i], ref[i], 8e-3, f"split-K tail {what}")
+    close(outs["split"][1], ref[1], 2e-3, "split-K BN partial sums")
