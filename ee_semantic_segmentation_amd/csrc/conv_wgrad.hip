@@ -226,9 +226,237 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 couts x 256 cins per filter tap, 8 waves (4 along cout x 2 along cin, 64 x 128 outputs per
+// wave), one block per CU, bf16.  Same pipeline as conv_big_kernel (conv_igemm.hip): LDS-DMA loads
+// in flight across raw barriers, two K tiles (64 pixels each) of LDS split into four 16-KiB half
+// tiles (cout halves W0/W1 of dY, cin halves XA/XB of X; [64 pixels][128 channels], 256-byte rows,
+// 64-byte XOR swizzle on the DMA source chunk), four quadrant phases per K tile, two wave groups
+// half a phase apart.  Fragments come from the transposing LDS read (K = pixels is the row index).
+// Split-K over pixel ranges with fp32 atomics into dW; K tiles whose tap-shifted rows are all in the
+// padding are skipped (block-uniform).
+constexpr int WHT = 64 * 256;              // half tile bytes
+constexpr int WB_LDS = 8 * WHT;
+
+#define WB_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WB_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef __attribute__((address_space(3))) s16x4* lds_tr;
+    __shared__ __attribute__((aligned(16))) char smem[WB_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int taps = p.R * p.S;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
+    const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
+    const int tap = bid % taps;
+    const int split = bid / taps;
+    const int co0 = co_t * 256, ci0 = ci_t * 256;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int dh = tr * p.dil - p.pad, dwv = ts * p.dil - p.pad;
+    const int ps = split * p.chunk;
+    const int pe = min(p.M, ps + p.chunk);
+    const int nk_all = (pe > ps) ? (pe - ps + 63) / 64 : 0;
+
+    // DMA role: one wave-instruction = 4 pixel rows x 256 B; per half tile a thread fetches rows drow, drow+32
+    const int drow = wave * 4 + (lane >> 4);
+    const int lc = ((lane & 15) ^ ((drow & 3) << 2)) * 8;        // local channel of the SOURCE chunk (swizzle)
+    int coW[2], ciX[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        coW[i] = (co0 + (lc >> 5) * 64 + i * 32 + (lc & 31)) * 2;
+        ciX[i] = (ci0 + (lc >> 6) * 128 + i * 64 + (lc & 63)) * 2;
+    }
+    int pm[2], pn[2], ph[2], pw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pm[q] = ps + q * 32 + drow;
+        pn[q] = pm[q] / p.HWout;
+        const int rem = pm[q] - pn[q] * p.HWout;
+        ph[q] = rem / p.Wout;
+        pw[q] = rem - ph[q] * p.Wout;
+    }
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+
+    auto step_valid = [&](int kt) {            // block-uniform: any tap-shifted source row of K tile kt inside the image?
+        const int m_first = ps + kt * 64;
+        const int m_last = min(pe, m_first + 64) - 1;
+        const int r_first = m_first / p.Wout, r_last = m_last / p.Wout;
+        for (int rr = r_first; rr <= r_last; ++rr) {
+            const int hi = (rr % p.Hout) * p.stride + dh;
+            if ((unsigned)hi < (unsigned)p.Hin) return true;
+        }
+        return false;
+    };
+    int kt = -1;
+    uint32_t voffDY[2] = {EESEG_OOB, EESEG_OOB}, voffX[2] = {EESEG_OOB, EESEG_OOB};
+    auto next_tile = [&]() -> bool {           // advance to the next K tile that is not all padding
+        int nx = kt + 1;
+        while (nx < nk_all && !step_valid(nx)) ++nx;
+        const bool live = nx < nk_all;
+        const int adv = (nx - (kt < 0 ? 0 : kt)) * 64;     // rows start at K tile 0
+        kt = nx;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (live) {
+                pm[q] += adv;
+                pw[q] += adv;
+                while (pw[q] >= p.Wout) { pw[q] -= p.Wout; ph[q] += 1; }
+                while (ph[q] >= p.Hout) { ph[q] -= p.Hout; pn[q] += 1; }
+            }
+            const bool in = live && pm[q] < pe;
+            voffDY[q] = in ? (uint32_t)(pm[q] * p.lddy * 2) : EESEG_OOB;
+            const int hi = ph[q] * p.stride + dh, wi = pw[q] * p.stride + dwv;
+            const bool ok = in && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
+            voffX[q] = ok ? (uint32_t)((((pn[q] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2) : EESEG_OOB;
+        }
+        return live;
+    };
+    const int w4 = __builtin_amdgcn_readfirstlane(wave) * 4;
+    auto dmaW = [&](int s, int i) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(smem + (s * 4 + 2 + i) * WHT + (q * 32 + w4) * 256), 16,
+                                                     (int)(voffDY[q] + coW[i]), 0, 0, 0);
+    };
+    auto dmaX = [&](int s, int h) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (s * 4 + h) * WHT + (q * 32 + w4) * 256), 16,
+                                                     (int)(voffX[q] + ciX[h]), 0, 0, 0);
+    };
+
+    const int wc = wave & 3, wp = wave >> 2;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int tq = (lane >> 2) & 3;                               // row of the 4x16 transposing-read block
+    const int chl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // first of my 4 channels inside a 32-wide fragment
+    const int trow = (8 * fh + tq) * 256;
+    // The transposing reads are inline asm: behind the builtin, hipcc (ROCm 7.2) waits vmcnt(0) before every LDS read
+    // that follows an LDS-DMA issue, which would drain the load pipeline twice per K tile.  The matching
+    // s_waitcnt lgkmcnt(0) (lgk_wait*) names the fragments as in/out operands so no MFMA can be scheduled above it.
+    auto rd = [&](const char* base, int lch, bf16x8 (&f)[4]) {
+        const uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(base + trow + ((lch * 2) ^ (tq << 6))));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            union { i32x2 h[2]; bf16x8 v; } u;
+            if (ks == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(u.h[1]) : "v"(a) : "memory");
+            } else if (ks == 1) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(u.h[0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:5120" : "=v"(u.h[1]) : "v"(a) : "memory");
+            } else if (ks == 2) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(u.h[0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(u.h[1]) : "v"(a) : "memory");
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(u.h[0]) : "v"(a) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:13312" : "=v"(u.h[1]) : "v"(a) : "memory");
+            }
+            f[ks] = u.v;
+        }
+    };
+    auto lgk_wait4 = [&](bf16x8 (&a)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : : "memory");
+    };
+    auto lgk_wait8 = [&](bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
+                     "+v"(b[2]), "+v"(b[3]) : : "memory");
+    };
+    auto lgk_wait12 = [&](bf16x8 (&a)[4], bf16x8 (&b)[4], bf16x8 (&c)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
+                     "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : : "memory");
+    };
+    auto mma4 = [&](const bf16x8 (&a)[4], const bf16x8 (&b0)[4], const bf16x8 (&b1)[4], f32x16& c0, f32x16& c1) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b0[ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b1[ks], c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // schedule and wait counts: see conv_big_kernel (phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2))
+    bool l0 = next_tile();
+    const bool any = l0;
+    dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);
+    bool l1 = next_tile();
+    dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);
+    WB_WAIT(6);
+    WB_BARRIER();
+    const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (lagging) WB_BARRIER();
+    int s = 0;
+    while (l0) {
+        const char* sb = smem + s * 4 * WHT;
+        bf16x8 w0[4], w1[4], xa0[4], xa1[4], xb0[4], xb1[4];
+        dmaX(s ^ 1, 1);
+        rd(sb + 2 * WHT, wc * 32 + chl, w0); rd(sb, wp * 64 + chl, xa0); rd(sb, wp * 64 + 32 + chl, xa1);
+        WB_WAIT(10);
+        WB_BARRIER();
+        lgk_wait12(w0, xa0, xa1);
+        mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+        WB_BARRIER();
+        rd(sb + 3 * WHT, wc * 32 + chl, w1);
+        WB_WAIT(8);
+        WB_BARRIER();
+        lgk_wait4(w1);
+        mma4(w1, xa0, xa1, acc[1][0], acc[1][1]);
+        WB_BARRIER();
+        const bool l2 = next_tile();
+        dmaX(s, 0); dmaW(s, 0);
+        rd(sb + WHT, wp * 64 + chl, xb0); rd(sb + WHT, wp * 64 + 32 + chl, xb1);
+        WB_BARRIER();
+        lgk_wait8(xb0, xb1);
+        mma4(w1, xb0, xb1, acc[1][2], acc[1][3]);
+        WB_BARRIER();
+        dmaW(s, 1);
+        WB_WAIT(10);
+        WB_BARRIER();
+        mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+        WB_BARRIER();
+        l0 = l1; l1 = l2; s ^= 1;
+    }
+    if (!lagging) WB_BARRIER();
+    WB_WAIT(0);
+    if (!any) return;
+
+    // ---- epilogue: fp32 atomics into dW[co][tap][ci] ---------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + wp * 128 + j * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wc * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
+                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)dst, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+int g_wgrad_big = 1;                // eeseg_set_wgrad_big(0|1)
+int g_wgrad_big_min_ktiles = 20;
 int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
 
 }  // namespace
+
+extern "C" int eeseg_set_wgrad_big(int on) {
+    g_wgrad_big = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return EESEG_OK;
+}
 
 extern "C" int eeseg_set_wgrad_target_blocks(int blocks) {
     EESEG_CHECK(blocks >= 64 && blocks <= 65535, EESEG_ERR_ARG, "set_wgrad_target_blocks: out of range");
@@ -266,6 +494,31 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     p.M = (int)M; p.HWout = a->Hout * a->Wout;
     p.co_tiles = (a->Cout + 127) / 128; p.ci_tiles = (a->Cin + 127) / 128;
     p.xbytes = (uint32_t)xbytes; p.dybytes = (uint32_t)dybytes;
+    if (g_wgrad_big && a->dtype == EESEG_BF16 && a->Cout % 256 == 0 && a->Cin % 256 == 0) {
+        // 256x256 tiles, one block per CU: choose the split count that fills whole rounds of 256 blocks best
+        p.co_tiles = a->Cout / 256; p.ci_tiles = a->Cin / 256;
+        const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
+        const long long max_splits = (M + 8 * 64 - 1) / (8 * 64);          // at least 8 K tiles per block
+        long long best = 1;
+        double best_eff = 0.0;
+        for (long long sp = 1; sp <= max_splits && tiles * sp <= 2048; ++sp) {
+            const long long blocks = tiles * sp;
+            const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
+            if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+        }
+        long long chunk = (M + best - 1) / best;
+        chunk = (chunk + 63) / 64 * 64;
+        const long long splits = (M + chunk - 1) / chunk;
+        p.splits = (int)splits; p.chunk = (int)chunk;
+        // short K ranges (few output tiles -> many splits) leave one block per CU mostly filling and draining its
+        // pipeline: measured break-even against the 128x128 kernel (2-3 blocks per CU) at ~20 K tiles per block
+        if (g_wgrad_big == 2 || chunk / 64 >= g_wgrad_big_min_ktiles) {
+            hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
+            EESEG_LAUNCH_CHECK();
+            return EESEG_OK;
+        }
+        p.co_tiles = (a->Cout + 127) / 128; p.ci_tiles = (a->Cin + 127) / 128;
+    }
     const int kp = 128 / es;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
     long long splits = (g_wgrad_target_blocks + tiles - 1) / tiles;

@@ -51,6 +51,9 @@ int eeseg_get_option(int key);   /* current value, or a negative error code */
 int eeseg_set_ew_grid_cap(int blocks);
 /* split-K sizing of the weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at */
 int eeseg_set_wgrad_target_blocks(int blocks);
+/* bf16 weight gradients with Cout % 256 == 0 and Cin % 256 == 0: 1 (default) = 256x256-tile kernel when every block
+ * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel) */
+int eeseg_set_wgrad_big(int on);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision

@@ -496,3 +496,36 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
         if ref[i] is not None:
             close(outs["split"][i], ref[i], 8e-3, f"split-K tail {what}")
     close(outs["split"][1], ref[1], 2e-3, "split-K BN partial sums")
+
+
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 33, 33, 256, 256, 3, 1, 12, 12),      # atrous: K tiles that are all padding get skipped
+    (1, 20, 20, 512, 256, 1, 1, 0, 1),        # 1x1, two cin tiles, M not a multiple of 64
+    (3, 19, 23, 256, 512, 3, 1, 1, 1),        # two cout tiles, ragged pixel count
+    (1, 8, 8, 256, 256, 3, 1, 2, 2),          # one K tile per block
+    (2, 31, 31, 256, 256, 3, 2, 1, 1),        # strided
+])
+def test_wgrad_256_tile_kernel_matches_the_128_tile_kernel(shape):
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W, Cin, Cout, k, s, p, d = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV).bfloat16()
+    Ho, Wo = K.conv_out_size(H, k, s, p, d), K.conv_out_size(W, k, s, p, d)
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV).bfloat16()
+    outs = {}
+    try:
+        for big in (0, 2):                      # 2 = force the 256x256 kernel whatever the K range per block
+            lib().eeseg_set_wgrad_big(big)
+            dw = K.conv_wgrad(x, dy, k, k, s, p, d)
+            dw2 = K.conv_wgrad(x, dy, k, k, s, p, d, out=dw.clone(), accumulate=True)
+            torch.cuda.synchronize()
+            outs[big] = (dw, dw2)
+    finally:
+        lib().eeseg_set_wgrad_big(1)
+    close(outs[2][0], outs[0][0], 2e-5, "dw")
+    close(outs[2][1], 2 * outs[0][0], 2e-5, "dw accumulate")
+    # and against fp32 torch on the same bf16 inputs
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Cout, Cin, k, k), dy.float().permute(0, 3, 1, 2),
+                                      stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
+    close(outs[2][0], ref, 2e-5, "dw vs torch")
