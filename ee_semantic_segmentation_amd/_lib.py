@@ -31,7 +31,8 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)] + \
                [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
-                                       "stride", "pad", "dil", "dtype", "accumulate")]
+                                       "stride", "pad", "dil", "dtype", "accumulate")] + \
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
 
 
 _vp, _i, _i64, _f, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
@@ -49,6 +50,7 @@ SIGNATURES = {
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_workspace": (_i64, []),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),
+    "eeseg_wgrad_workspace": (_i64, []),
     "eeseg_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_pack_weight_multi": (_i, [_vp, _i, _i, _vp]),
     "eeseg_pack_matrix": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -480,6 +480,9 @@ constexpr int SLAB_FLOATS = BIGT * BIGT;
 #define BIG_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define BIG_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+__device__ long long* g_dbg_stamps = nullptr;
+#define STAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0) g_dbg_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+
 template <int MODE>
 __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef bf16_t T;
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
 
+    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = xcd_remap(blockIdx.x, gridDim.x);
     const int nsplit = (MODE == 1) ? p.ksplit : 1;
@@ -533,14 +537,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         __syncthreads();
         unsigned vmask[4] = {0u, 0u, 0u, 0u};
         {
-            for (int t = 0; t < taps; ++t) {
-                const int r = t / p.S, s = t - r * p.S;
+            int t = 0;
+            for (int r = 0; r < p.R; ++r)
+                for (int s = 0; s < p.S; ++s, ++t) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int hi = hb[k] + r * p.tstep_h, wi = wb[k] + s * p.tstep_w;
-                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) vmask[k] |= 1u << t;
+                    for (int k = 0; k < 4; ++k) {
+                        const int hi = hb[k] + r * p.tstep_h, wi = wb[k] + s * p.tstep_w;
+                        if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) vmask[k] |= 1u << t;
+                    }
                 }
-            }
             unsigned mine = vmask[0] | vmask[1] | vmask[2] | vmask[3];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
@@ -635,10 +640,12 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         //     group has consumed its reads);
         //   * the wait that retires the loads of phase Q sits in phase Q-1 after the reads, before the barrier.
         // Issue order per iteration: phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2).
+        STAMP(1);
         next_tile(); dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);      // K tile 0
         next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);                  // K tile 1 without XB
         BIG_WAIT(6);
         BIG_BARRIER();
+        STAMP(2);
         const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
         if (lagging) BIG_BARRIER();
         for (int t = 0; t < nk; ++t) {
@@ -675,6 +682,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         if (!lagging) BIG_BARRIER();
         BIG_WAIT(0);                       // trailing out-of-range DMAs still write (zeros) into LDS
         BIG_BARRIER();
+        STAMP(3);
     }
 
     if constexpr (MODE == 1) {             // partial sums of this K range, register layout: 1 KiB per wave store
@@ -718,11 +726,13 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                 T v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][j][4 * g + e] * sc[e] + sh[e]);
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<T*>(stage + px * BIG_SROW) + cl) = bf16x4{v[0], v[1], v[2], v[3]};
+                // 8-byte XOR on rows 8..15 (mod 16): lanes fr and fr+8 of a 16-lane store group would share banks
+                *reinterpret_cast<bf16x4*>(stage + px * BIG_SROW + ((cl * 2) ^ (((px >> 3) & 1) << 3))) = bf16x4{v[0], v[1], v[2], v[3]};
             }
         }
     }
     __syncthreads();
+    STAMP(4);
 
     // ---- epilogue 2: row-major read back, residual/ReLU, stats, coalesced 16-byte stores ----
     const int c = tid & 31, r0 = tid >> 5;
@@ -733,44 +743,55 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     T* yout = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.residual);
     const bool full = p.vec_ok && (cg + 8 <= p.Cout);
-    for (int row = r0; row < BIGT; row += 16) {
-        const int m = m0 + row;
-        if (m >= p.M) break;
-        union { i32x4 q; T e[8]; } u;
-        u.q = *reinterpret_cast<const i32x4*>(stage + row * BIG_SROW + c * 16);
-        T* v = u.e;
-        if (res != nullptr) {
-            if (full) {
-                union { i32x4 q; T e[8]; } ur;
-                ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+    i32x4 rq[16];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
+    for (int it = 0; it < 16; ++it) {                      // all LDS reads first (the accumulators are dead: registers are free)
+        const int row = r0 + 16 * it;
+        const i32x4 q = *reinterpret_cast<const i32x4*>(stage + row * BIG_SROW + c * 16);
+        rq[it] = ((row >> 3) & 1) ? i32x4{q[2], q[3], q[0], q[1]} : q;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = r0 + 16 * it;
+        const int m = m0 + row;
+        if (m < p.M) {
+            union { i32x4 q; T e[8]; } u;
+            u.q = rq[it];
+            T* v = u.e;
+            if (res != nullptr) {
+                if (full) {
+                    union { i32x4 q; T e[8]; } ur;
+                    ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = to_f32(v[e]);
+                    s1[e] += f;
+                    s2[e] += f * f;
+                }
+            }
+            if (full) {
+                *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+                    if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
             }
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
-        }
-        if (p.stats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = to_f32(v[e]);
-                s1[e] += f;
-                s2[e] += f * f;
-            }
-        }
-        if (full) {
-            *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
         }
     }
+    STAMP(5);
     if (p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -997,6 +1018,10 @@ extern "C" int eeseg_set_option(int key, int value) {
     }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);
     return EESEG_ERR_ARG;
+}
+
+extern "C" int eeseg_debug_set_stamps(long long* ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1;
 }
 
 extern "C" int eeseg_get_option(int key) {

@@ -17,6 +17,7 @@ struct WgP {
     int lddy;
     int M, HWout, co_tiles, ci_tiles, splits, chunk;
     uint32_t xbytes, dybytes;
+    float* slabs;     // 256x256 kernel: per-block fp32 partial tiles (register layout) instead of atomics, or NULL
 };
 
 template <typename T>
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
 // 256 couts x 256 cins per filter tap, 8 waves (4 along cout x 2 along cin, 64 x 128 outputs per
 // wave), one block per CU, bf16.  Same pipeline as conv_big_kernel (conv_igemm.hip): LDS-DMA loads
 // in flight across raw barriers, two K tiles (64 pixels each) of LDS split into four 16-KiB half
-// tiles (cout halves W0/W1 of dY, cin halves XA/XB of X; [64 pixels][128 channels], 256-byte rows,
+// tiles (cout halves W0/W1 of dY, cin halves XA/XB of X, 128 contiguous channels each so that every DMA row is two
+// whole cache lines; wave (wc, wp) owns couts i*128 + wc*32.. and cins h*128 + wp*64..; [64 pixels][128 channels], 256-byte rows,
 // 64-byte XOR swizzle on the DMA source chunk), four quadrant phases per K tile, two wave groups
 // half a phase apart.  Fragments come from the transposing LDS read (K = pixels is the row index).
 // Split-K over pixel ranges with fp32 atomics into dW; K tiles whose tap-shifted rows are all in the
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int taps = p.R * p.S;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int unit = bid;                      // = ((split * taps + tap) * ci_tiles + ci_t) * co_tiles + co_t
     const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
     const int tap = bid % taps;
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     int coW[2], ciX[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        coW[i] = (co0 + (lc >> 5) * 64 + i * 32 + (lc & 31)) * 2;
-        ciX[i] = (ci0 + (lc >> 6) * 128 + i * 64 + (lc & 63)) * 2;
+        coW[i] = (co0 + i * 128 + lc) * 2;        // a half tile = 128 CONTIGUOUS channels: whole 128-byte lines per DMA row
+        ciX[i] = (ci0 + i * 128 + lc) * 2;
     }
     int pm[2], pn[2], ph[2], pw[2];
 #pragma unroll
@@ -429,17 +432,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     }
     if (!lagging) WB_BARRIER();
     WB_WAIT(0);
+    if (p.slabs) {
+        // ---- epilogue A (opt-in, reproducible): partial tile -> slab[unit] in register layout (1 KiB per wave store);
+        // wgrad_slab_reduce_kernel sums the splits in a fixed order.  Measured 2-5 % slower than the atomics below on the
+        // 3x3 layers (the atomics of one block overlap the K loops of the others; the reduce is one more launch)
+        float* ws = p.slabs + (size_t)unit * 65536 + (wave * 32) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(ws + ((i * 4 + j) * 4 + g) * 256) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        return;
+    }
     if (!any) return;
 
-    // ---- epilogue: fp32 atomics into dW[co][tap][ci] ---------------------------
+    // ---- epilogue B: fp32 atomics into dW[co][tap][ci] -------------------------
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ci = ci0 + wp * 128 + j * 32 + fr;
+            const int ci = ci0 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + fr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wc * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int co = co0 + i * 128 + wc * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
                 float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
                 __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)dst, acc[i][j][e]);
             }
@@ -447,14 +465,57 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     }
 }
 
+// dW[co][tap][ci] += sum over the K splits of one 256x256 tile, slabs in the producing kernel's register layout.
+// grid = tiles x 8 (one block per producing wave = 32 KiB of every slab), 256 threads.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p) {
+    const int taps = p.R * p.S;
+    const int tiles = p.co_tiles * p.ci_tiles * taps;
+    int tl = blockIdx.x >> 3;
+    const int wave = blockIdx.x & 7;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int wc = wave & 3, wp = wave >> 2, fr = lane & 31, fh = lane >> 5;
+    const float* ws = p.slabs + (size_t)tl * 65536 + (wave * 32) * 256 + lane * 4;
+    const int co_t = tl % p.co_tiles; tl /= p.co_tiles;
+    const int ci_t = tl % p.ci_tiles;
+    const int tap = tl / p.ci_tiles;
+#pragma unroll
+    for (int ij = 0; ij < 2; ++ij) {
+        const int i = (sub * 2 + ij) >> 2, j = (sub * 2 + ij) & 3;
+        f32x4 a[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.splits; ++s) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                a[g] += *reinterpret_cast<const f32x4*>(ws + (size_t)s * tiles * 65536 + ((i * 4 + j) * 4 + g) * 256);
+        }
+        const int ci = ci_t * 256 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + fr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = co_t * 256 + i * 128 + wc * 32 + k + 8 * g + 4 * fh;
+                float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
+                *dst += a[g][k];
+            }
+    }
+}
+
 int g_wgrad_big = 1;                // eeseg_set_wgrad_big(0|1)
 int g_wgrad_big_min_ktiles = 20;
+int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
 int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
 
 }  // namespace
 
+extern "C" int64_t eeseg_wgrad_workspace(void) {
+    return 2048ll * 65536 * 4;           // tiles * splits <= 2048 slabs of 256 KiB
+}
+
 extern "C" int eeseg_set_wgrad_big(int on) {
-    g_wgrad_big = on < 0 ? 0 : (on > 2 ? 2 : on);
+    g_wgrad_slabs = (on & 4) ? 1 : 0;
+    on &= 3;
+    g_wgrad_big = on > 2 ? 2 : on;
     return EESEG_OK;
 }
 
@@ -487,6 +548,7 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         EESEG_HIP(hipMemsetAsync(a->dw, 0, (size_t)a->Cout * taps * a->Cin * sizeof(float), st));
 
     WgP p;
+    p.slabs = nullptr;
     p.x = a->x; p.dy = a->dy; p.dw = a->dw;
     p.N = a->N; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin;
     p.Hout = a->Hout; p.Wout = a->Wout; p.Cout = a->Cout; p.R = a->R; p.S = a->S;
@@ -513,7 +575,11 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         // short K ranges (few output tiles -> many splits) leave one block per CU mostly filling and draining its
         // pipeline: measured break-even against the 128x128 kernel (2-3 blocks per CU) at ~20 K tiles per block
         if (g_wgrad_big == 2 || chunk / 64 >= g_wgrad_big_min_ktiles) {
+            const long long need = tiles * splits * 65536ll * 4;
+            p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
+                          ? reinterpret_cast<float*>(a->workspace) : nullptr;
             hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
+            if (p.slabs) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8)), dim3(256), 0, st, p);
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }

@@ -303,40 +303,34 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
 }
 
-// fused: reduce the conv-epilogue partials of 64 channels (sum and sum of squares) and finalize them
-// in the same block (local BatchNorm: no all-reduce between the two steps)
+// fused: reduce the conv-epilogue partials of 16 channels (sum and sum of squares; 64 tile lanes x 16 channel lanes)
+// and finalize them in the same block (local BatchNorm: no all-reduce between the two steps)
 __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partials, int tiles, double count,
                                                                   const float* gamma, const float* beta, float eps,
                                                                   float momentum, float* running_mean, float* running_var,
                                                                   float* mean_invstd, float* scale_shift, int C) {
-    __shared__ double sred[2][16][64];
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    __shared__ double sred[2][16][16];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-        int t = g;
-        for (; t + 16 < tiles; t += 32) {
-            a0 += partials[((long long)t * 2 + 0) * C + c];
-            b0 += partials[((long long)t * 2 + 1) * C + c];
-            a1 += partials[((long long)(t + 16) * 2 + 0) * C + c];
-            b1 += partials[((long long)(t + 16) * 2 + 1) * C + c];
-        }
-        for (; t < tiles; t += 16) {
+        float a0 = 0.f, b0 = 0.f;
+        for (int t = tl; t < tiles; t += 64) {
             a0 += partials[((long long)t * 2 + 0) * C + c];
             b0 += partials[((long long)t * 2 + 1) * C + c];
         }
-        s1 = (double)a0 + (double)a1;
-        s2 = (double)b0 + (double)b1;
+        s1 = (double)a0;
+        s2 = (double)b0;
     }
-    sred[0][g][lane] = s1;
-    sred[1][g][lane] = s2;
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if ((threadIdx.x & 63) < 16) { sred[0][wave][cl] = s1; sred[1][wave][cl] = s2; }
     __syncthreads();
-    if (g == 0 && c < C) {
+    if (threadIdx.x < 16 && c < C) {
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { t1 += sred[0][i][lane]; t2 += sred[1][i][lane]; }
-        // same arithmetic as bn_finalize_kernel on the fp32-rounded sums (so both paths agree bit for bit)
+        for (int i = 0; i < 16; ++i) { t1 += sred[0][i][cl]; t2 += sred[1][i][cl]; }
+        // same arithmetic as bn_finalize_kernel on the fp32-rounded sums
         const double mean = (double)(float)t1 / count;
         double var = (double)(float)t2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -913,7 +907,7 @@ extern "C" int eeseg_bn_reduce_finalize(const float* partials, int tiles, double
     EESEG_CHECK(partials && scale_shift && tiles > 0 && C > 0 && count > 0, EESEG_ERR_ARG, "bn_reduce_finalize: bad argument");
     EESEG_CHECK((running_mean == nullptr) == (running_var == nullptr), EESEG_ERR_ARG,
                 "bn_reduce_finalize: running_mean/var must both be given or both be NULL");
-    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partials, tiles,
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, tiles,
                        count, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift, C);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;

@@ -260,6 +260,9 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
         _allreduce(cfg, sums)
         count *= cfg.world()
         mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+    elif part.shape[0] > 2048:      # very many tiles (stem): two-level reduction, then finalize
+        mi, ss = K.bn_finalize(K.reduce_partials(part), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean,
+                               bn.running_var)
     else:       # local BatchNorm: partial reduction and finalize fused in one launch
         mi, ss = K.bn_reduce_finalize(part, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
     bn._pending_batches += 1

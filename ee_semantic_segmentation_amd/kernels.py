@@ -108,6 +108,20 @@ def _conv_ws(device):
     return t
 
 
+WGRAD_SLABS = False      # True + eeseg_set_wgrad_big(.. | 4): reproducible K-split combine of the 256x256 wgrad kernel
+
+
+def _wgrad_ws(device):
+    """Fixed scratch of the 256x256 weight-gradient kernel (K-split slabs); one per device and per stream role
+    (the weight gradient may run on the side stream while the conv scratch is in use on the main one)."""
+    key = ("wgrad", str(device))
+    t = _ws.get(key)
+    if t is None:
+        t = torch.empty(int(lib().eeseg_wgrad_workspace()), dtype=torch.uint8, device=device)
+        _ws[key] = t
+    return t
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -199,6 +213,9 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
     a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cin, Ho, Wo, Cout, R, S
     a.stride, a.pad, a.dil, a.dtype, a.accumulate = stride, pad, dil, _dt(x), int(accumulate)
+    if WGRAD_SLABS and a.dtype == BF16 and Cout % 256 == 0 and Cin % 256 == 0:
+        ws = _wgrad_ws(x.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     ev = _prof_begin()
     check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
     if ev is not None:

@@ -52,7 +52,8 @@ int eeseg_set_ew_grid_cap(int blocks);
 /* split-K sizing of the weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at */
 int eeseg_set_wgrad_target_blocks(int blocks);
 /* bf16 weight gradients with Cout % 256 == 0 and Cin % 256 == 0: 1 (default) = 256x256-tile kernel when every block
- * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel) */
+ * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel); +4 = combine the K splits through
+ * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics */
 int eeseg_set_wgrad_big(int on);
 
 /* ---------------------------------------------------------------- conv ----
@@ -90,7 +91,11 @@ typedef struct {
     const void* x; const void* dy; float* dw;
     int N, Hin, Win, Cin, Hout, Wout, Cout, R, S;
     int stride, pad, dil, dtype, accumulate;
+    void* workspace;              /* optional scratch (NULL = none) for eeseg_set_wgrad_big(.. | 4): the 256x256-tile kernel then combines */
+    int64_t workspace_bytes;      /* its K splits through plain-store slabs + a fixed-order reduce (bitwise reproducible) instead of fp32
+                                     atomics; eeseg_wgrad_workspace() bytes suffice */
 } eeseg_wgrad_args;
+int64_t eeseg_wgrad_workspace(void);
 int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
 
 /* fp32 master weight -> compute-dtype KRSC (`w_fwd` [Cout_pad][R][S][Cin], may be

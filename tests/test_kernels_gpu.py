@@ -447,7 +447,7 @@ def test_bn_reduce_finalize_fused_equals_two_step():
         mi1, ss1 = K.bn_finalize(K.reduce_partials(part), cnt, gamma, beta, 1e-5, 0.1, rm1, rv1)
         mi2, ss2 = K.bn_reduce_finalize(part, cnt, gamma, beta, 1e-5, 0.1, rm2, rv2)
         for a, b, what in [(mi1, mi2, "mean/invstd"), (ss1, ss2, "scale/shift"), (rm1, rm2, "rm"), (rv1, rv2, "rv")]:
-            close(b, a, 2e-6, f"{what} tiles={tiles} C={Cc}")
+            close(b, a, 1e-5, f"{what} tiles={tiles} C={Cc}")
 
 
 @pytest.mark.parametrize("shape", [
@@ -515,16 +515,21 @@ def test_wgrad_256_tile_kernel_matches_the_128_tile_kernel(shape):
     dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV).bfloat16()
     outs = {}
     try:
-        for big in (0, 2):                      # 2 = force the 256x256 kernel whatever the K range per block
+        for big in (0, 2, 6):                   # 2 = force the 256x256 kernel (K splits by atomics), 6 = same through slabs
             lib().eeseg_set_wgrad_big(big)
+            K.WGRAD_SLABS = big == 6
             dw = K.conv_wgrad(x, dy, k, k, s, p, d)
             dw2 = K.conv_wgrad(x, dy, k, k, s, p, d, out=dw.clone(), accumulate=True)
+            if big == 6:                        # slab combine sums the K splits in a fixed order: bitwise reproducible
+                assert torch.equal(K.conv_wgrad(x, dy, k, k, s, p, d), dw)
             torch.cuda.synchronize()
             outs[big] = (dw, dw2)
     finally:
         lib().eeseg_set_wgrad_big(1)
-    close(outs[2][0], outs[0][0], 2e-5, "dw")
-    close(outs[2][1], 2 * outs[0][0], 2e-5, "dw accumulate")
+        K.WGRAD_SLABS = False
+    for mode in (2, 6):
+        close(outs[mode][0], outs[0][0], 2e-5, f"dw (mode {mode})")
+        close(outs[mode][1], 2 * outs[0][0], 2e-5, f"dw accumulate (mode {mode})")
     # and against fp32 torch on the same bf16 inputs
     ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Cout, Cin, k, k), dy.float().permute(0, 3, 1, 2),
                                       stride=s, padding=p, dilation=d).permute(0, 2, 3, 1)
