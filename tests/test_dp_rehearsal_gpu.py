@@ -55,6 +55,10 @@ def test_rccl_collectives_in_graph_match_local_run(monkeypatch):
     try:
         got = _run(True)
     finally:
+        # the captured graph (with its RCCL kernels) must be gone and the device idle before the communicator is torn down
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
     assert np.all(np.isfinite(got))
     # same dropout seeds, same data: the first step agrees to fp32 rounding; the SyncBN path sums the
