@@ -67,7 +67,7 @@ SIGNATURES = {
                                 _vp, _i, _vp]),
     "eeseg_scale_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp]),
     "eeseg_maxpool3x3s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "eeseg_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "eeseg_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_sum_hw": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _i64, _vp]),
     "eeseg_broadcast_hw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "eeseg_dropout": (_i, [_vp, _vp, _i64, _f, _u64, _vp, _i, _vp]),

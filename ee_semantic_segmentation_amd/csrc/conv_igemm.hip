@@ -480,17 +480,12 @@ constexpr int SLAB_FLOATS = BIGT * BIGT;
 #define BIG_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define BIG_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-__device__ long long* g_dbg_stamps = nullptr;
-#define STAMP(i) do { if (g_dbg_stamps && threadIdx.x == 0) g_dbg_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-
 template <int MODE>
 __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef bf16_t T;
     typedef Mma<T>::Frag Frag;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
-
-    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = xcd_remap(blockIdx.x, gridDim.x);
     const int nsplit = (MODE == 1) ? p.ksplit : 1;
@@ -640,12 +635,10 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         //     group has consumed its reads);
         //   * the wait that retires the loads of phase Q sits in phase Q-1 after the reads, before the barrier.
         // Issue order per iteration: phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2).
-        STAMP(1);
         next_tile(); dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);      // K tile 0
         next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);                  // K tile 1 without XB
         BIG_WAIT(6);
         BIG_BARRIER();
-        STAMP(2);
         const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
         if (lagging) BIG_BARRIER();
         for (int t = 0; t < nk; ++t) {
@@ -682,7 +675,6 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         if (!lagging) BIG_BARRIER();
         BIG_WAIT(0);                       // trailing out-of-range DMAs still write (zeros) into LDS
         BIG_BARRIER();
-        STAMP(3);
     }
 
     if constexpr (MODE == 1) {             // partial sums of this K range, register layout: 1 KiB per wave store
@@ -732,7 +724,6 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         }
     }
     __syncthreads();
-    STAMP(4);
 
     // ---- epilogue 2: row-major read back, residual/ReLU, stats, coalesced 16-byte stores ----
     const int c = tid & 31, r0 = tid >> 5;
@@ -791,7 +782,6 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
             }
         }
     }
-    STAMP(5);
     if (p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1018,10 +1008,6 @@ extern "C" int eeseg_set_option(int key, int value) {
     }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);
     return EESEG_ERR_ARG;
-}
-
-extern "C" int eeseg_debug_set_stamps(long long* ptr) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_stamps), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1;
 }
 
 extern "C" int eeseg_get_option(int key) {

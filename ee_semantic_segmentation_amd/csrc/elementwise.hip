@@ -133,24 +133,26 @@ __global__ void im2col_nchw_kernel(const float* __restrict__ x, T* col, int N, i
         const long long t = m / Wo;
         const int ho = (int)(t % Ho);
         const int n = (int)(t / Ho);
-        T out[8];
+        // (tap, ci) of the first k once, then incrementally: no per-element divisions; one vector store per thread
+        const int k0 = kg * 8;
+        int tap = k0 / C, ci = k0 - tap * C;
+        int r = tap / S, s = tap - r * S;
+        const int hb = ho * stride - pad, wb = wo * stride - pad;
+        const float* xn = x + (long long)n * C * H * W;
+        union { T e[8]; i32x4 q4[sizeof(T) == 2 ? 1 : 2]; } out;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int k = kg * 8 + e;
             float v = 0.f;
-            if (k < K) {
-                const int ci = k % C;
-                const int tap = k / C;
-                const int r = tap / S, s = tap - r * S;
-                const int hi = ho * stride - pad + r, wi = wo * stride - pad + s;
-                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                    v = x[(((long long)n * C + ci) * H + hi) * W + wi];
+            if (k0 + e < K) {
+                const int hi = hb + r, wi = wb + s;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = xn[((long long)ci * H + hi) * W + wi];
             }
-            out[e] = from_f32<T>(v);
+            out.e[e] = from_f32<T>(v);
+            if (++ci == C) { ci = 0; if (++s == S) { s = 0; ++r; } }
         }
-        T* dst = col + m * Kpad + kg * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = out[e];
+        i32x4* dst = reinterpret_cast<i32x4*>(col + m * Kpad + k0);
+        dst[0] = out.q4[0];
+        if constexpr (sizeof(T) == 4) dst[1] = out.q4[1];
     }
 }
 
@@ -563,6 +565,66 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* x, const T* d
 #pragma unroll
                 for (int e = 0; e < EPC; ++e)
                     if (bidx[e] == h * W + w) acc[e] += to_f32(g.e[e]);
+            }
+        }
+        Vec<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.e[e] = from_f32<T>(acc[e]);
+        st16(dx + (((long long)n * H + h) * W + w) * C + ch * EPC, o);
+    }
+}
+
+// The same with the forward output y = maxpool(x) at hand: an input element can only receive a window's
+// gradient if it EQUALS that window's maximum, so the 9-tap rescan per window (36 loads per element) shrinks to
+// one load of y per window plus, for the elements that do equal it, a scan of the EARLIER window positions for a tie.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_y_kernel(const T* x, const T* y, const T* dy, T* dx, int N, int H, int W,
+                                                            int C, int Ho, int Wo) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int cpr = C / EPC;
+    const long long total = (long long)N * H * W * cpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        long long t = i / cpr;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const Vec<T> v = ld16(x + (((long long)n * H + h) * W + w) * C + ch * EPC);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        const int ho_lo = h / 2, ho_hi = (h + 1) / 2;
+        const int wo_lo = w / 2, wo_hi = (w + 1) / 2;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                const Vec<T> ym = ld16(y + (((long long)n * Ho + ho) * Wo + wo) * C + ch * EPC);
+                unsigned eq = 0u;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) eq |= (to_f32(v.e[e]) == to_f32(ym.e[e])) ? (1u << e) : 0u;
+                if (!eq) continue;
+                // first-maximum rule: drop the lanes for which an earlier window position holds the same value
+                const int r_me = h - (ho * 2 - 1), s_me = w - (wo * 2 - 1);
+                for (int r = 0; r <= r_me && eq; ++r) {
+                    const int hi = ho * 2 - 1 + r;
+                    if ((unsigned)hi >= (unsigned)H) continue;
+                    const int s_end = (r == r_me) ? s_me : 3;
+                    for (int sx = 0; sx < s_end && eq; ++sx) {
+                        const int wi = wo * 2 - 1 + sx;
+                        if ((unsigned)wi >= (unsigned)W) continue;
+                        const Vec<T> u = ld16(x + (((long long)n * H + hi) * W + wi) * C + ch * EPC);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e)
+                            if (to_f32(u.e[e]) == to_f32(ym.e[e])) eq &= ~(1u << e);
+                    }
+                }
+                if (!eq) continue;
+                const Vec<T> g = ld16(dy + (((long long)n * Ho + ho) * Wo + wo) * C + ch * EPC);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if ((eq >> e) & 1u) acc[e] += to_f32(g.e[e]);
             }
         }
         Vec<T> o;
@@ -1099,8 +1161,8 @@ extern "C" int eeseg_maxpool3x3s2(const void* x, void* y, int N, int H, int W, i
     return EESEG_OK;
 }
 
-extern "C" int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho,
-                                      int Wo, int dtype, void* stream) {
+extern "C" int eeseg_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W, int C,
+                                      int Ho, int Wo, int dtype, void* stream) {
     EESEG_CHECK(x && dy && dx, EESEG_ERR_ARG, "maxpool_bwd: null pointer");
     EESEG_CHECK(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, EESEG_ERR_ARG, "maxpool_bwd: bad output size");
     CHECK_ROWS("maxpool_bwd x", x, C, C, dtype);
@@ -1109,6 +1171,17 @@ extern "C" int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, i
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
     const int g = ew_grid((long long)N * H * W * (C / epc));
+    if (y != nullptr) {
+        CHECK_ROWS("maxpool_bwd y", y, C, C, dtype);
+        if (dtype == EESEG_BF16)
+            hipLaunchKernelGGL((maxpool_bwd_y_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)y,
+                               (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, Ho, Wo);
+        else
+            hipLaunchKernelGGL((maxpool_bwd_y_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (const float*)y,
+                               (const float*)dy, (float*)dx, N, H, W, C, Ho, Wo);
+        EESEG_LAUNCH_CHECK();
+        return EESEG_OK;
+    }
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy,
                            (bf16_t*)dx, N, H, W, C, Ho, Wo);

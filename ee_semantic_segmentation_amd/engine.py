@@ -379,12 +379,12 @@ def stem_fwd(cfg, img, conv, bn, train):
     else:
         y, st = conv_bn_eval(cfg, col, conv, bn, True, x_is_col=True), None
     p = K.maxpool3x3s2(y)
-    return p, (st, y)
+    return p, (st, y, p)        # p is layer1's saved input anyway: keeping the reference costs nothing
 
 
 def stem_bwd(cfg, state, dp, conv, bn):
-    st, y = state
-    dy = K.maxpool3x3s2_bwd(y, dp)
+    st, y, p = state
+    dy = K.maxpool3x3s2_bwd(y, dp, p)
     _, _, dw, dg, db = conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=False, x_is_col=True)
     return dw, dg, db
 

@@ -408,11 +408,13 @@ def maxpool3x3s2(x):
     return y
 
 
-def maxpool3x3s2_bwd(x, dy):
+def maxpool3x3s2_bwd(x, dy, y=None):
+    """y = maxpool3x3s2(x) when the caller still holds it (4x fewer loads)."""
     N, H, W, Cc = x.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty_like(x)
-    check(lib().eeseg_maxpool3x3s2_bwd(_p(x), _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, _dt(x), _stream()),
+    assert y is None or (y.shape == dy.shape and y.dtype == x.dtype and y.is_contiguous())
+    check(lib().eeseg_maxpool3x3s2_bwd(_p(x), _p(y), _p(dy), _p(dx), N, H, W, Cc, Ho, Wo, _dt(x), _stream()),
           "eeseg_maxpool3x3s2_bwd")
     return dx
 

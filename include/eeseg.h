@@ -172,10 +172,11 @@ int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int ldy, const 
 
 /* --------------------------------------------------- pooling / misc ------- */
 /* 3x3 stride-2 pad-1 max pool (ResNet stem, from_deepv3_new.py:77-79); backward
- * routes each window's gradient to its FIRST maximum (torch CPU tie rule). */
+ * routes each window's gradient to its FIRST maximum (torch CPU tie rule).  `y` = the forward output (may be
+ * NULL: the window maxima are then recomputed, ~4x the loads). */
 int eeseg_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype, void* stream);
-int eeseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo,
-                           int dtype, void* stream);
+int eeseg_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int N, int H, int W, int C, int Ho,
+                           int Wo, int dtype, void* stream);
 /* per-image column sum: y[n][c] = scale * sum_hw x[n][hw][c] (ASPPPooling's
  * AdaptiveAvgPool2d(1) with scale = 1/HW; also the backward of the broadcast) */
 int eeseg_sum_hw(const void* x, int ldx, void* y, int N, int HW, int C, float scale, int dtype, void* workspace,

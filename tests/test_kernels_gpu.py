@@ -199,6 +199,8 @@ def test_maxpool_fwd_bwd_with_ties(dtype):
     close(nchw(yd), y, 0.0 + 1e-7, "maxpool fwd")
     dx = K.maxpool3x3s2_bwd(xd, nhwc(gy).to(DEV, dtype))
     close(nchw(dx), x.grad, tol(dtype), "maxpool bwd")
+    dx2 = K.maxpool3x3s2_bwd(xd, nhwc(gy).to(DEV, dtype), yd)          # with the forward output: same routing
+    assert torch.equal(dx2, dx)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
