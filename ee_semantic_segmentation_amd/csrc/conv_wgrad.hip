@@ -16,6 +16,8 @@ struct WgP {
     int N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad, dil;
     int lddy;
     int M, HWout, co_tiles, ci_tiles, splits, chunk;
+    int q64, r64;     // 64 pixels = q64 output rows + r64 columns
+    int qk, rk, fast_wrap;   // 128x128 kernel: the same for its K step (64 bf16 / 32 f32 pixels); qk + 1 <= Hout
     uint32_t xbytes, dybytes;
     float* slabs;     // 256x256 kernel: per-block fp32 partial tiles (register layout) instead of atomics, or NULL
 };
@@ -82,28 +84,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ci_ok[i] ? basex + i * (TPR * 16) : EESEG_OOB), 0, 0);
         }
     };
-    auto advance = [&](int steps) {
-        pm += steps * KP;
-        pw += steps * KP;
-        while (pw >= p.Wout) { pw -= p.Wout; ph += 1; }
-        while (ph >= p.Hout) { ph -= p.Hout; pn += 1; }
-    };
-    // Block-uniform: does K step `kt` contain a pixel row whose tap-shifted source row is inside the
-    // image?  For the atrous convs (|dh| = 12/24/36 on 65 rows) up to 55 % of the steps of the off-centre
-    // tap rows multiply only zero padding and are skipped.
-    auto step_valid = [&](int kt) {
-        const int m_first = ps + kt * KP;
-        const int m_last = min(pe, m_first + KP) - 1;
-        const int r_first = m_first / p.Wout, r_last = m_last / p.Wout;     // global output-row indices
-        for (int rr = r_first; rr <= r_last; ++rr) {
-            const int hi = (rr % p.Hout) * p.stride + dh;
-            if ((unsigned)hi < (unsigned)p.Hin) return true;
+    // K-step iterator: additions only (KP pixels = qk output rows + rk columns, host-computed).  Block-uniform part:
+    // does the step contain a pixel row whose tap-shifted source row is inside the image?  For the atrous convs
+    // (|dh| = 12/24/36 on 65 rows) up to 55 % of the steps of the off-centre tap rows multiply only zero padding
+    // and are skipped.
+    int kpos = 0;                              // the K step the rows currently sit on
+    int t_h, t_w;                              // image row / column of that step's first pixel (block-uniform)
+    {
+        const int rem0 = ps % p.HWout;
+        t_h = rem0 / p.Wout;
+        t_w = rem0 - t_h * p.Wout;
+    }
+    auto tile_valid = [&]() {
+        int r = t_h, rem = t_w + KP - 1;
+        bool ok = false;
+        for (;;) {
+            ok = ok || ((unsigned)(r * p.stride + dh) < (unsigned)p.Hin);
+            if (rem < p.Wout) break;
+            rem -= p.Wout;
+            r = (r + 1 == p.Hout) ? 0 : r + 1;
         }
-        return false;
+        return ok;
     };
-    auto next_valid = [&](int kt) {
-        while (kt < nk && !step_valid(kt)) ++kt;
-        return kt;
+    auto step_one = [&]() {
+        ++kpos;
+        t_w += p.rk; t_h += p.qk;
+        if (t_w >= p.Wout) { t_w -= p.Wout; ++t_h; }
+        while (t_h >= p.Hout) t_h -= p.Hout;
+        pm += KP; pw += p.rk; ph += p.qk;
+        if (pw >= p.Wout) { pw -= p.Wout; ++ph; }
+        if (p.fast_wrap) {                     // qk + 1 <= Hout: one conditional subtraction wraps the row counter
+            if (ph >= p.Hout) { ph -= p.Hout; ++pn; }
+        } else {
+            while (ph >= p.Hout) { ph -= p.Hout; ++pn; }
+        }
+    };
+    auto seek_valid = [&]() {                  // stay on the current step if it is valid, else move to the next valid one
+        while (kpos < nk && !tile_valid()) step_one();
+        return kpos;
     };
     auto store_tile = [&](int buf) {
         const int sw = (lrow & 3) << 6;
@@ -124,22 +142,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int wr = wave >> 1, wcI = wave & 1;     // cout half, cin half
-    int kt = next_valid(0);
+    int kt = seek_valid();
     const bool any = kt < nk;
     if (any) {
-        advance(kt);
         load_tile();
         store_tile(0);
     }
     __syncthreads();
     int cur = 0;
     while (kt < nk) {
-        const int nx = next_valid(kt + 1);
+        step_one();
+        const int nx = seek_valid();
         const bool has_next = nx < nk;
-        if (has_next) {
-            advance(nx - kt);
-            load_tile();
-        }
+        if (has_next) load_tile();
         const char* a = sDY + cur * TILE;
         const char* b = sX + cur * TILE;
         if constexpr (ES == 2) {
@@ -283,32 +298,48 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
 
-    auto step_valid = [&](int kt) {            // block-uniform: any tap-shifted source row of K tile kt inside the image?
-        const int m_first = ps + kt * 64;
-        const int m_last = min(pe, m_first + 64) - 1;
-        const int r_first = m_first / p.Wout, r_last = m_last / p.Wout;
-        for (int rr = r_first; rr <= r_last; ++rr) {
-            const int hi = (rr % p.Hout) * p.stride + dh;
-            if ((unsigned)hi < (unsigned)p.Hin) return true;
+    // K-tile iterator.  Everything advances by additions only (64 pixels = q64 rows + r64 columns, host-computed;
+    // the host guarantees q64 + 1 <= Hout so one conditional subtraction wraps a row/image counter): the iterator
+    // runs in the LDS-read slot of a phase and must stay far below the 256 MFMA cycles of the other wave group.
+    int t_h, t_w;                              // block-uniform: image row / column of the first pixel of K tile kt
+    {
+        const int rem0 = ps % p.HWout;
+        t_h = rem0 / p.Wout;
+        t_w = rem0 - t_h * p.Wout;
+    }
+    auto tile_valid = [&]() {                  // any tap-shifted source row of the 64 pixels inside the image?
+        int r = t_h, rem = t_w + 63;
+        bool ok = false;
+        for (;;) {
+            ok = ok || ((unsigned)(r * p.stride + dh) < (unsigned)p.Hin);
+            if (rem < p.Wout) break;
+            rem -= p.Wout;
+            r = (r + 1 == p.Hout) ? 0 : r + 1;
         }
-        return false;
+        return ok;
     };
     int kt = -1;
     uint32_t voffDY[2] = {EESEG_OOB, EESEG_OOB}, voffX[2] = {EESEG_OOB, EESEG_OOB};
     auto next_tile = [&]() -> bool {           // advance to the next K tile that is not all padding
-        int nx = kt + 1;
-        while (nx < nk_all && !step_valid(nx)) ++nx;
-        const bool live = nx < nk_all;
-        const int adv = (nx - (kt < 0 ? 0 : kt)) * 64;     // rows start at K tile 0
-        kt = nx;
+        bool live;
+        for (;;) {
+            if (kt >= 0) {                     // (kt == -1: the rows already sit on K tile 0)
+                t_w += p.r64; t_h += p.q64;
+                if (t_w >= p.Wout) { t_w -= p.Wout; ++t_h; }
+                if (t_h >= p.Hout) t_h -= p.Hout;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    pm[q] += 64; pw[q] += p.r64; ph[q] += p.q64;
+                    if (pw[q] >= p.Wout) { pw[q] -= p.Wout; ++ph[q]; }
+                    if (ph[q] >= p.Hout) { ph[q] -= p.Hout; ++pn[q]; }
+                }
+            }
+            ++kt;
+            live = kt < nk_all;
+            if (!live || tile_valid()) break;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (live) {
-                pm[q] += adv;
-                pw[q] += adv;
-                while (pw[q] >= p.Wout) { pw[q] -= p.Wout; ph[q] += 1; }
-                while (ph[q] >= p.Hout) { ph[q] -= p.Hout; pn[q] += 1; }
-            }
             const bool in = live && pm[q] < pe;
             voffDY[q] = in ? (uint32_t)(pm[q] * p.lddy * 2) : EESEG_OOB;
             const int hi = ph[q] * p.stride + dh, wi = pw[q] * p.stride + dwv;
@@ -556,7 +587,9 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     p.M = (int)M; p.HWout = a->Hout * a->Wout;
     p.co_tiles = (a->Cout + 127) / 128; p.ci_tiles = (a->Cin + 127) / 128;
     p.xbytes = (uint32_t)xbytes; p.dybytes = (uint32_t)dybytes;
-    if (g_wgrad_big && a->dtype == EESEG_BF16 && a->Cout % 256 == 0 && a->Cin % 256 == 0) {
+    p.q64 = 64 / a->Wout; p.r64 = 64 % a->Wout;
+    p.qk = (128 / es) / a->Wout; p.rk = (128 / es) % a->Wout; p.fast_wrap = (p.qk + 1 <= a->Hout) ? 1 : 0;
+    if (g_wgrad_big && a->dtype == EESEG_BF16 && a->Cout % 256 == 0 && a->Cin % 256 == 0 && p.q64 + 1 <= a->Hout) {
         // 256x256 tiles, one block per CU: choose the split count that fills whole rounds of 256 blocks best
         p.co_tiles = a->Cout / 256; p.ci_tiles = a->Cin / 256;
         const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;

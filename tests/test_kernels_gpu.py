@@ -505,7 +505,7 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     (2, 33, 33, 256, 256, 3, 1, 12, 12),      # atrous: K tiles that are all padding get skipped
     (1, 20, 20, 512, 256, 1, 1, 0, 1),        # 1x1, two cin tiles, M not a multiple of 64
     (3, 19, 23, 256, 512, 3, 1, 1, 1),        # two cout tiles, ragged pixel count
-    (1, 8, 8, 256, 256, 3, 1, 2, 2),          # one K tile per block
+    (1, 12, 12, 256, 256, 3, 1, 2, 2),        # few K tiles per block, 5 image rows per K tile
     (2, 31, 31, 256, 256, 3, 2, 1, 1),        # strided
 ])
 def test_wgrad_256_tile_kernel_matches_the_128_tile_kernel(shape):
