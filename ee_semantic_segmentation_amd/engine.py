@@ -153,6 +153,9 @@ class GradArena:
             elif what == "cls_b":
                 self.kernel_view[obj] = seg
                 obj.grad = seg[:obj.numel()]
+            elif what == "vec":
+                self.kernel_view[obj] = seg
+                obj.grad = seg
             else:                      # conv weight (incl. stem), stored channels_last = KRSC
                 co, ci, r, s_ = obj.shape
                 if not (obj.is_contiguous(memory_format=torch.channels_last) or (r == 1 and s_ == 1)):
@@ -172,12 +175,14 @@ class GradArena:
     @staticmethod
     def _head_entries(h):
         e = []
-        aspp = h[0]
+        aspp = h.aspp
         for seq in aspp.convs:
             conv, bn = (seq[1], seq[2]) if type(seq).__name__ == "ASPPPooling" else (seq[0], seq[1])
             e += [(conv.weight, "w"), (bn, "bn")]
-        e += [(aspp.project[0].weight, "w"), (aspp.project[1], "bn"), (h[1].weight, "w"), (h[2], "bn"),
-              (h[4].weight, "cls_w"), (h[4].bias, "cls_b")]
+        e += [(aspp.project[0].weight, "w"), (aspp.project[1], "bn"), (h.conv3.weight, "w"), (h.bn3, "bn"),
+              (h.cls.weight, "cls_w"), (h.cls.bias, "cls_b")]
+        if h.pre is not None:          # my_branch(bottleneck=...): finishes last in backward
+            e += [(h.pre.weight, "w"), (h.pre.bias, "vec")]
         return e
 
 
@@ -189,7 +194,7 @@ def pack_all(net, dtype):
     convs = []
     for mod in net.modules():
         if type(mod).__name__ == "Conv2d" and mod.weight.shape[1] != 3:        # the stem goes through packed_stem
-            is_cls = mod.bias is not None
+            is_cls = mod.bias is not None and mod.__dict__.get("_eeseg_role") != "pre"
             convs.append((mod, torch.float32 if is_cls else dtype, CPAD if is_cls else None))
     groups = {}
     for mod, dt, cp in convs:
@@ -428,9 +433,39 @@ def bottleneck_bwd(cfg, state, dout, blk):
 
 
 # ------------------------------------------------------------------- head ----
+def conv_bias_fwd(cfg, x, conv):
+    """1x1 conv + bias, no BN / activation (my_branch's bottleneck conv, from_deepv3_new.py:24)."""
+    wf, _ = packed(conv, x.dtype)
+    s, p, d = _geom(conv)
+    return K.conv_fwd(x, wf, s, p, d, shift=conv.bias.detach())[0]
+
+
+def conv_bias_bwd(cfg, x, dy, conv):
+    """-> (dx, dw, dbias); dw/dbias are None when they were written into the gradient arena."""
+    gvw, gvb = cfg.gview(conv.weight), cfg.gview(conv.bias)
+    r = conv.weight.shape[2]
+    s, p, d = _geom(conv)
+    if gvw is not None:
+        if cfg.accumulate:
+            gvb.add_(K.colsum(dy))
+        else:
+            K.colsum(dy, out=gvb)
+        K.conv_wgrad(x, dy, r, r, s, p, d, out=gvw, accumulate=cfg.accumulate or cfg.arena.prezeroed)
+        dw = db = None
+    else:
+        db = K.colsum(dy)
+        dw = K.conv_wgrad(x, dy, r, r, s, p, d).permute(0, 3, 1, 2)
+    _, wb = packed(conv, x.dtype)
+    dx = K.conv_dgrad(dy, wb, x.shape[1:3], s, p, d)
+    return dx, dw, db
+
+
 def head_fwd(cfg, x, head, train):
     """DeepLabHead on NHWC features -> low-res logits [N,h,w,CPAD] fp32."""
-    aspp = head[0]
+    aspp = head.aspp
+    x_in = x
+    if head.pre is not None:
+        x = conv_bias_fwd(cfg, x_in, head.pre)
     N, h, w, cin = x.shape
     nb = len(aspp.convs)                      # 1x1 + atrous convs + pooling
     mid = aspp.project[0].weight.shape[0]
@@ -463,13 +498,13 @@ def head_fwd(cfg, x, head, train):
             pr_d = K.dropout(pr, pdrop, seed, cfg.step_dev(pr.device))
         else:
             pr_d = pr
-        q, stq = conv_bn_fwd(cfg, pr_d, head[1], head[2], True)
+        q, stq = conv_bn_fwd(cfg, pr_d, head.conv3, head.bn3, True)
     else:
         pr_d = conv_bn_eval(cfg, cat, proj[0], proj[1], True)
-        q = conv_bn_eval(cfg, pr_d, head[1], head[2], True)
+        q = conv_bn_eval(cfg, pr_d, head.conv3, head.bn3, True)
         stj = stq = None
     # classifier 1x1 (+bias) always in fp32, Cout padded to CPAD
-    cls = head[4]
+    cls = head.cls
     q32 = q if q.dtype == torch.float32 else K.cast(q, torch.float32)
     wf, _ = packed(cls, torch.float32, CPAD)
     bias = cls.__dict__.get("_eeseg_bias_pad")
@@ -480,18 +515,18 @@ def head_fwd(cfg, x, head, train):
         bias = (bkey, bp)
         cls.__dict__["_eeseg_bias_pad"] = bias
     logits, _ = K.conv_fwd(q32, wf, shift=bias[1])
-    state = (x, cat, states, stj, seed, stq, q32) if train else None
+    state = (x, cat, states, stj, seed, stq, q32, x_in) if train else None
     return logits, state
 
 
 def head_bwd(cfg, state, dlogits, head):
     """Returns (dx, grads in head.param_list() order)."""
-    x, cat, states, stj, seed, stq, q32 = state
-    aspp = head[0]
+    x, cat, states, stj, seed, stq, q32, x_in = state
+    aspp = head.aspp
     nb = len(aspp.convs)
     mid = aspp.project[0].weight.shape[0]
     N, h, w, cin = x.shape
-    cls = head[4]
+    cls = head.cls
     ncls = cls.weight.shape[0]
     # classifier
     gvb, gvw = cfg.gview(cls.bias), cfg.gview(cls.weight)
@@ -510,7 +545,7 @@ def head_bwd(cfg, state, dlogits, head):
     if cfg.compute_dtype != torch.float32:
         dq = K.cast(dq, cfg.compute_dtype)
     # 3x3 conv + BN + ReLU
-    dpr_d, _, dw3, dg3, db3 = conv_bn_bwd(cfg, stq, dq, head[1], head[2])
+    dpr_d, _, dw3, dg3, db3 = conv_bn_bwd(cfg, stq, dq, head.conv3, head.bn3)
     proj = aspp.project
     dpr = K.dropout(dpr_d, proj[3].p, seed, cfg.step_dev(dpr_d.device)) if seed is not None else dpr_d
     dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
@@ -527,5 +562,8 @@ def head_bwd(cfg, state, dlogits, head):
     K.broadcast_hw(dg_.view(N, cin), dx, scale=1.0 / (h * w), accumulate=True)
     grads_convs += [dwp, dgp, dbp]
     grads = grads_convs + [dwj, dgj, dbj, dw3, dg3, db3, dwc, dbias]
+    if head.pre is not None:
+        dx, dwpre, dbpre = conv_bias_bwd(cfg, x_in, dx, head.pre)
+        grads += [dwpre, dbpre]
     cfg.unit_done(head)
     return dx, grads

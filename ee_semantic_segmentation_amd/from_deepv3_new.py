@@ -46,14 +46,14 @@ def block_macs(blk, h, w):
 
 
 def head_macs(head, h, w):
-    tot = 0
-    aspp = head[0]
+    tot = conv_macs(head.pre, h, w)[0] if head.pre is not None else 0
+    aspp = head.aspp
     for seq in aspp.convs:
         if isinstance(seq, ASPPPooling):
             tot += seq[1].in_channels * seq[1].out_channels      # pooled 1x1 conv on a 1x1 map
         else:
             tot += conv_macs(seq[0], h, w)[0]
-    tot += conv_macs(aspp.project[0], h, w)[0] + conv_macs(head[1], h, w)[0] + conv_macs(head[4], h, w)[0]
+    tot += conv_macs(aspp.project[0], h, w)[0] + conv_macs(head.conv3, h, w)[0] + conv_macs(head.cls, h, w)[0]
     return tot
 
 
@@ -77,13 +77,25 @@ def model_macs(net, H, W):
 
 # ------------------------------------------------------------- my_branch ------
 class my_branch(DeepLabHead):
-    """from_deepv3_new.py:15-39 without the optional bottleneck conv (not used by
-    either main_* script, main_bradeepv3.py:129-132 keeps branch_params=None)."""
+    """from_deepv3_new.py:15-39: a DeepLabHead with its own atrous rates / width and, with `bottleneck`, a leading
+    1x1 conv (+bias, no BN, no activation) that narrows the features first.  Child indices (= state_dict keys) are
+    the reference's: [0: bottleneck conv,] ASPP, 3x3 conv, BN, ReLU, 1x1 classifier."""
 
     def __init__(self, nin_channels, num_classes, atrous_rates, nout_channels, bottleneck=None, cfg=None, **kw):
-        if bottleneck:
-            raise NotImplementedError("my_branch(bottleneck=...) is outside the accelerated hot path")
-        super().__init__(nin_channels, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg)
+        if not bottleneck:
+            super().__init__(nin_channels, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg)
+            return
+        if bottleneck % 64:
+            raise ValueError("my_branch: bottleneck width must be a multiple of 64 channels (K tile of the conv kernels)")
+        super().__init__(bottleneck, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg)
+        rest = list(self.children())
+        pre = Conv2d(nin_channels, bottleneck, 1, bias=True)
+        pre.__dict__["_eeseg_role"] = "pre"
+        for k in list(self._modules):
+            del self._modules[k]
+        for i, m in enumerate([pre] + rest):
+            self.add_module(str(i), m)
+        self._off = 1
 
 
 # ------------------------------------------------------------ exit logits -----

@@ -238,14 +238,40 @@ class DeepLabHead(nn.Sequential):
         self.__dict__["cfg"] = cfg
         self.num_classes = num_classes
 
+    # structural accessors (the engine and the gradient arena go through these, so a head with a leading
+    # bottleneck conv - my_branch(bottleneck=...) - only shifts the Sequential indices)
+    _off = 0
+
+    @property
+    def pre(self):
+        return self[0] if self._off else None
+
+    @property
+    def aspp(self):
+        return self[self._off]
+
+    @property
+    def conv3(self):
+        return self[self._off + 1]
+
+    @property
+    def bn3(self):
+        return self[self._off + 2]
+
+    @property
+    def cls(self):
+        return self[self._off + 4]
+
     def param_list(self):
         ps = []
-        aspp = self[0]
+        aspp = self.aspp
         for i, seq in enumerate(aspp.convs):
             conv, bn = (seq[1], seq[2]) if isinstance(seq, ASPPPooling) else (seq[0], seq[1])
             ps += [conv.weight, bn.weight, bn.bias]
         ps += [aspp.project[0].weight, aspp.project[1].weight, aspp.project[1].bias,
-               self[1].weight, self[2].weight, self[2].bias, self[4].weight, self[4].bias]
+               self.conv3.weight, self.bn3.weight, self.bn3.bias, self.cls.weight, self.cls.bias]
+        if self.pre is not None:
+            ps += [self.pre.weight, self.pre.bias]
         return ps
 
     def forward(self, x):

@@ -162,9 +162,27 @@ def conv_macs(mods, img_dim, cin=3):
     return out
 
 
-def head_macs(cin, num_classes, h, w, mid=256):
-    per_px = cin * mid + 3 * 9 * cin * mid + 5 * mid * mid + 9 * mid * mid + mid * num_classes
-    return per_px * h * w + cin * mid  # + pooled 1x1 conv on a 1x1 map
+def head_macs(cin, num_classes, h, w, mid=256, n_atrous=3, bottleneck=None):
+    pre = 0
+    if bottleneck:
+        pre = cin * bottleneck * h * w
+        cin = bottleneck
+    per_px = cin * mid + n_atrous * 9 * cin * mid + (n_atrous + 2) * mid * mid + 9 * mid * mid + mid * num_classes
+    return pre + per_px * h * w + cin * mid  # + pooled 1x1 conv on a 1x1 map
+
+
+class my_branch(nn.Sequential):
+    """Restatement of from_deepv3_new.py:15-39: a head with its own atrous rates / width and, with `bottleneck`,
+    a leading 1x1 conv (+bias, no BN, no activation)."""
+
+    def __init__(self, nin_channels, num_classes, atrous_rates, nout_channels, bottleneck=None, **kwargs):
+        rest = lambda cin: [ASPP(cin, atrous_rates, nout_channels),
+                            nn.Conv2d(nout_channels, nout_channels, 3, padding=1, bias=False),
+                            nn.BatchNorm2d(nout_channels), nn.ReLU(), nn.Conv2d(nout_channels, num_classes, 1)]
+        if bottleneck:
+            super().__init__(nn.Conv2d(nin_channels, bottleneck, 1), *rest(bottleneck))
+        else:
+            super().__init__(*rest(nin_channels))
 
 
 class branchyDeepv3(nn.Module):
@@ -176,8 +194,21 @@ class branchyDeepv3(nn.Module):
     """
 
     def __init__(self, base_type="deeplabv3_resnet101", n=1, img_dim=256, count_branches=True,
-                 skip=0, num_classes=21, split_after=None):
+                 skip=0, num_classes=21, split_after=None, branch_params=None):
         super().__init__()
+        custom = isinstance(branch_params, dict) and all(k in branch_params for k in ("nout_channels", "atrous_rates"))
+
+        def gen_branch(cin):              # from_deepv3_new.py:126-131
+            if custom:
+                return my_branch(nin_channels=cin, num_classes=num_classes, **branch_params)
+            return DeepLabHead(cin, num_classes)
+
+        def branch_cost(cin, fh):
+            if custom:
+                return head_macs(cin, num_classes, fh, fh, branch_params["nout_channels"],
+                                 len(branch_params["atrous_rates"]), branch_params.get("bottleneck"))
+            return head_macs(cin, num_classes, fh, fh)
+
         blocks = (3, 4, 6, 3) if re.search("resnet50", base_type) else (3, 4, 23, 3)
         backbone = _resnet_backbone(blocks)
         self.classifier = DeepLabHead(2048, num_classes)
@@ -202,11 +233,11 @@ class branchyDeepv3(nn.Module):
                     hit = (n > k) and tot > cost > flop_pos * (k + 1 + skip)
                 if hit:
                     base_model.append(nn.Sequential(*section))
-                    branches.append(DeepLabHead(cin, num_classes))
+                    branches.append(gen_branch(cin))
                     names.append(name)
                     section = []
                     fh = self._feat_hw(name, img_dim)
-                    extra += head_macs(cin, num_classes, fh, fh)
+                    extra += branch_cost(cin, fh)
         base_model.append(nn.Sequential(*section))
         self.base_model = nn.ModuleList(base_model)
         self.branches = nn.ModuleList(branches)
