@@ -51,3 +51,34 @@ class mIoU:
         if self.nan_safe:
             cIoU = torch.nan_to_num(cIoU, nan=1.0)
         return (cIoU.sum() / self.C).cpu()
+
+
+class img_mIoU:
+    """Per-image mean IoU over the classes present in the target (compute_mIoU.py:38-63), one image per call, on
+    the fused upsample+argmax+confusion kernel: IoU_i = TP_i / (TP_i + FP_i + FN_i) for every class with
+    TP_i + FN_i > 0; when the image has void pixels the void label is one more "present class" with IoU 0
+    (it is in `unique(target)` and never predicted), exactly as the reference counts it."""
+
+    def __init__(self):
+        self.accumulator = [0.0, 0]
+
+    def __call__(self, y_pred, target, exit_index=None):
+        return self.forward(y_pred, target, exit_index)
+
+    def forward(self, y_pred, target, exit_index=None):
+        if not isinstance(y_pred, ExitLogits) and y_pred.dim() == 3:
+            y_pred = y_pred.unsqueeze(0)
+        t = target.reshape(1, *target.shape[-2:])
+        counts = confusion_counts(y_pred, t, exit_index).to(torch.float32)
+        tp, fp, fn = counts[0], counts[1], counts[2]
+        present = (tp + fn) > 0
+        iou = torch.where(present, tp / (tp + fp + fn), torch.zeros_like(tp))
+        n_void = t.numel() - int((tp + fn).sum().item())
+        n_classes = int(present.sum().item()) + (1 if n_void > 0 else 0)
+        self.accumulator[0] += (iou.sum() / n_classes).item()
+        self.accumulator[1] += 1
+
+    def compute(self):
+        if self.accumulator[1] <= 0:
+            return float("nan")
+        return self.accumulator[0] / self.accumulator[1]

@@ -48,6 +48,33 @@ class mIoU:
         return np.float32(ciou.sum() / self.C)
 
 
+class img_mIoU:
+    """compute_mIoU.py:38-63 - per-image mean IoU over the classes PRESENT IN THE TARGET, averaged over images.
+
+    One image per call.  `unique(target)` includes the void label when void pixels exist: that "class" is never
+    predicted, so it contributes IoU 0 and still counts in the denominator (reproduced).  union counts every pixel
+    that is target-i or predicted-i, so a void pixel predicted i enlarges class i's union."""
+
+    def __init__(self):
+        self.acc = [0.0, 0]
+
+    def __call__(self, y_pred, target):
+        y_pred = np.asarray(y_pred)
+        if y_pred.ndim == 4:
+            y_pred = y_pred.argmax(axis=1).squeeze()
+        target = np.asarray(target).squeeze()
+        classes = np.unique(target.reshape(-1))
+        s = 0.0
+        for i in classes:
+            gt, pr = target == i, y_pred == i
+            s += np.float32(np.sum(gt & pr)) / np.float32(np.sum(gt | pr))
+        self.acc[0] += float(np.float32(s) / np.float32(classes.shape[0]))
+        self.acc[1] += 1
+
+    def compute(self):
+        return float("nan") if self.acc[1] <= 0 else self.acc[0] / self.acc[1]
+
+
 def block_reduce(a, size, func):
     """skimage.measure.block_reduce semantics (documented behaviour; skimage is
     absent -> PARITY UNPINNED): pad with 0 up to a multiple of the block, then

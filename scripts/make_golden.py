@@ -96,6 +96,24 @@ def main():
                         miou=np.float64(val), acc=m.accumulator.numpy())
     print("selfcheck mIoU", val)
 
+    # ---- per-image mIoU (compute_mIoU.py:38-63): streamed over single images, void pixels present in some ----
+    cases = []
+    for seed, C, H, W, void_frac in [(10, 21, 19, 23, 0.1), (11, 19, 16, 16, 0.0), (12, 5, 33, 20, 0.3), (13, 21, 8, 8, 0.05)]:
+        torch.manual_seed(seed)
+        m = RM.img_mIoU()
+        ys, ts = [], []
+        for _ in range(3):
+            y = torch.randn(1, C, H, W)
+            t = torch.randint(0, C, [1, H, W])
+            t[torch.rand(1, H, W) < void_frac] = C
+            m(y, t)
+            ys.append(y.numpy()); ts.append(t.numpy())
+        cases.append((np.concatenate(ys), np.concatenate(ts), m.compute()))
+    np.savez_compressed(os.path.join(OUT, "img_miou.npz"),
+                        **{f"y{i}": c[0] for i, c in enumerate(cases)}, **{f"t{i}": c[1] for i, c in enumerate(cases)},
+                        expected=np.array([c[2] for c in cases], dtype=np.float64))
+    print("img_mIoU", [round(c[2], 9) for c in cases])
+
 
 if __name__ == "__main__":
     main()

@@ -78,3 +78,14 @@ def test_block_reduce_semantics():
     mn = metrics_ref.block_reduce(a, (2, 2), np.min)
     np.testing.assert_array_equal(mx, [[6, 8], [10, 12]])
     np.testing.assert_array_equal(mn, [[1, 3], [0, 0]])   # zero padding wins the min
+
+
+def test_img_miou_oracle_matches_reference_vectors(golden_dir):
+    """compute_mIoU.img_mIoU run by scripts/make_golden.py on 4 x 3 seeded images (void pixels in three cases)."""
+    from oracle.metrics_ref import img_mIoU
+    g = np.load(os.path.join(golden_dir, "img_miou.npz"))
+    for i, want in enumerate(g["expected"]):
+        m = img_mIoU()
+        for y, t in zip(g[f"y{i}"], g[f"t{i}"]):
+            m(y[None], t[None])
+        assert abs(m.compute() - want) < 1e-6, (i, m.compute(), want)
