@@ -294,6 +294,44 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __re
         }
 }
 
+// ---------------------------------------- argmax of two exits -> contingency table ----
+// Per image n: hist[n][a][b] = number of pixels where exit A predicts class a and exit B class b (both upsampled
+// to H x W on the fly).  Everything the similarity gates need (MSE / NMI / variation of information between the
+// label maps of consecutive exits, sim_metrics.py + eval_br_sim.py:41-48) is a function of this C x C table.
+__global__ __launch_bounds__(256) void argmax_pair_hist_kernel(const float* __restrict__ lra, const float* __restrict__ lrb,
+                                                               int ldc, int C, int h, int w, int H, int W, int* hist) {
+    __shared__ int sh_[CMAX * CMAX];
+    for (int i = threadIdx.x; i < CMAX * CMAX; i += blockDim.x) sh_[i] = 0;
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int total = H * W;
+    const bool active = lane32 < C;
+    for (int p = blockIdx.x * 8 + half; p < total; p += gridDim.x * 8) {
+        const int x = p % W, y = p / W;
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        float za = active ? interp(lra, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        float zb = active ? interp(lrb, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        int ia = lane32, ib = lane32;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {            // first maximum wins (torch.argmax)
+            const float oa = __shfl_xor(za, o), ob = __shfl_xor(zb, o);
+            const int ja = __shfl_xor(ia, o), jb = __shfl_xor(ib, o);
+            if (oa > za || (oa == za && ja < ia)) { za = oa; ia = ja; }
+            if (ob > zb || (ob == zb && jb < ib)) { zb = ob; ib = jb; }
+        }
+        if (lane32 == 0) atomicAdd(&sh_[ia * CMAX + ib], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int a = i / C, b = i - a * C;
+        const int v = sh_[a * CMAX + b];
+        if (v) atomicAdd(&hist[((size_t)n * C + a) * C + b], v);
+    }
+}
+
 // ---------------------------------------------------------- entropy gate ----
 __global__ __launch_bounds__(256) void entropy_map_kernel(const float* __restrict__ lr, int ldc, int N, int C, int h,
                                                           int w, int H, int W, float* emap) {
@@ -432,6 +470,20 @@ extern "C" int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int
     EESEG_CHECK((counts && target) || pred, EESEG_ERR_ARG, "argmax_confusion: nothing to compute");
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
                        logits_lr, ldc, target, N, C, h, w, H, W, (int*)counts, pred);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_argmax_pair_hist(const float* logits_a, const float* logits_b, int ldc, int N, int C, int h, int w,
+                                      int H, int W, int32_t* hist, void* stream) {
+    const float* logits_lr = logits_a;
+    CHECK_LR("argmax_pair_hist");
+    EESEG_CHECK(logits_b && hist && ((uintptr_t)logits_b & 15) == 0, EESEG_ERR_ARG, "argmax_pair_hist: bad pointer");
+    long long blocks = ((long long)H * W + 8 * 16 - 1) / (8 * 16);      // >= 16 pixels per half wave
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(argmax_pair_hist_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_a,
+                       logits_b, ldc, C, h, w, H, W, (int*)hist);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

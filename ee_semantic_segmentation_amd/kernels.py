@@ -517,6 +517,17 @@ def argmax_confusion(lr, C_, target, H, W, counts=None, want_pred=False):
     return counts, pred
 
 
+def argmax_pair_hist(lr_a, lr_b, C_, H, W, hist=None):
+    """Per-image contingency table [N,C,C] int32 of the upsampled argmax maps of two exits."""
+    N, h, w, ldc = _lr_dims(lr_a)
+    assert _lr_dims(lr_b) == (N, h, w, ldc)
+    if hist is None:
+        hist = torch.zeros((N, C_, C_), dtype=torch.int32, device=lr_a.device)
+    check(lib().eeseg_argmax_pair_hist(_p(lr_a), _p(lr_b), ldc, N, C_, h, w, H, W, _p(hist), _stream()),
+          "eeseg_argmax_pair_hist")
+    return hist
+
+
 def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1):
     N, h, w, ldc = _lr_dims(lr)
     ent = torch.empty((N,), dtype=torch.float32, device=lr.device)

@@ -226,6 +226,12 @@ int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target
  * mask [N,H,W] int64; target may be NULL when only pred is wanted. */
 int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
                            int H, int W, int32_t* counts, int64_t* pred, void* stream);
+/* Fused upsample + argmax of TWO exits -> per-image contingency table hist[N][C][C] int32 (+= per call):
+ * hist[n][a][b] = pixels where exit A predicts a and exit B predicts b.  The similarity gates between consecutive
+ * exits (MSE / NMI / variation of information of the label maps: sim_metrics.py:41-120, eval_br_sim.py:41-48,
+ * ee_dnn_op.py:86) are functions of this table, so no label map leaves the device. */
+int eeseg_argmax_pair_hist(const float* logits_a, const float* logits_b, int ldc, int N, int C, int h, int w, int H, int W,
+                           int32_t* hist, void* stream);
 /* Fused upsample + softmax + normalised entropy (+ s x s max/min block pool) +
  * mean per image (eval_br_ent.py:19-36).  entropy_out[N] fp32; exit_flag[N]
  * int32 = (entropy < tau) stays on device (eval_br_ent.py:60, ee_dnn_op_ne.py:81).

@@ -62,3 +62,54 @@ def test_br_evaluator_and_progressive_inference():
     with torch.no_grad():
         full = net(X.unsqueeze(0).to(DEV))
     assert torch.equal(never["last"], full[-1, 0].argmax(0).cpu())
+
+
+def test_similarity_gated_evaluator_and_progressive_inference():
+    """eval_br_sim.br_evaluator + ee_dnn_op.eval_ee_deeplabv3 (similarity gate between consecutive exits): dict
+    contracts, the two limits of the threshold, and the gate values against the numpy oracle on the same maps."""
+    from ee_semantic_segmentation_amd.eval_br_sim import br_evaluator, gate_function
+    from ee_semantic_segmentation_amd.ee_dnn_op import eval_ee_deeplabv3
+    from ee_semantic_segmentation_amd.get_seg_datasets import SyntheticSeg
+    from oracle import sim_ref as R
+    C, img = 21, 65
+    net = _net(3, img, C).eval()                 # 4 exits: gates compare (b1,b2) and (b2,b3)
+    ds = SyntheticSeg(4, img, C, seed=3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2)
+    keys = {"b1_mIoU", "b1_count", "b2_mIoU", "b2_count", "b3_mIoU", "b3_count", "mIoU_out", "count_out", "mIoU_gl",
+            "out_gl", "t"}
+    for metric, never, always in (("mse", -1.0, 1e9), ("vi", -1.0, 1e9), ("h_xy", -1.0, 1e9), ("h_yx", -1.0, 1e9),
+                                  ("nmi", 1e9, -1.0)):
+        lo = br_evaluator(net, 4, C, loader, DEV, metric, never, ignore=(0,))
+        hi = br_evaluator(net, 4, C, loader, DEV, metric, always, ignore=(0,))
+        assert set(lo) == keys
+        assert lo["count_out"] == 4 and lo["b1_count"] == lo["b2_count"] == 0 and lo["out_gl"] == 4
+        # the first gated pair compares exits 0 and 1 and the image leaves AT exit 1: out_count[1] -> "b2_count"
+        # (eval_br_sim.py:41-48,61-63); exit 0 can never be left at, it only provides the first map
+        assert hi["b2_count"] == 4 and hi["b1_count"] == 0 and hi["count_out"] == 0
+    with pytest.raises(NotImplementedError):
+        gate_function("ssim")
+    # gate values vs the oracle on the materialised label maps
+    X, _ = ds[1]
+    with torch.no_grad():
+        full = net(X.unsqueeze(0).to(DEV)).cpu().numpy()          # [E,1,C,H,W]
+    from ee_semantic_segmentation_amd import kernels as K
+    net.fused_outputs = True
+    with torch.no_grad():
+        el = net(X.unsqueeze(0).to(DEV))
+    net.fused_outputs = False
+    t01 = K.argmax_pair_hist(el.lowres[0].contiguous(), el.lowres[1].contiguous(), C, img, img)[0].double()
+    assert abs(gate_function("mse")[0](t01) - R.mse(full[0], full[1])) < 1e-9
+    assert abs(gate_function("vi", (0,))[0](t01) - R.vi(full[0], full[1], (0,))) < 1e-9
+    assert abs(gate_function("nmi")[0](t01) - R.nmi(full[0], full[1])) < 1e-9
+    # progressive operator
+    f_mse = gate_function("mse")[0]
+    never = eval_ee_deeplabv3(net, f_mse, -1.0, device=DEV)(X)
+    always = eval_ee_deeplabv3(net, f_mse, 1e9, device=DEV)(X)
+    assert never["n"] == 4 and torch.equal(never["exit"], never["last"]) and never["exit_flops"] == never["last_flops"]
+    assert always["n"] == 2                      # branch 0 is only the reference map; branch 1 is the first that can exit
+    assert always["exit_flops_2"] < always["exit_flops"] < always["last_flops"]
+    assert torch.equal(always["exit"], torch.from_numpy(full[1, 0].argmax(0)))
+    assert set(always) >= {"exit", "exit_flops", "exit_flops_2", "edge_flops", "edge_flops_2", "n", "last", "last_flops",
+                           "last_flops_2"}
+    stop = eval_ee_deeplabv3(net, f_mse, 1e9, device=DEV, stop_at_exit=True)(X)
+    assert "last" not in stop and torch.equal(stop["exit"], always["exit"])

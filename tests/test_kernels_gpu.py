@@ -563,3 +563,43 @@ def test_img_miou_matches_oracle_and_reference_vectors():
     m(el, t.to(DEV), 0)
     r(el.stack()[0].cpu().numpy(), t.numpy())
     assert abs(m.compute() - r.compute()) < 1e-6
+
+
+def test_similarity_gates_from_pair_histogram():
+    """MSE / NMI / VI between the label maps of two exits from the fused pair-histogram kernel vs the numpy oracle
+    (restated scikit-image formulas: parity unpinned, see oracle/sim_ref.py) + the identities the metrics must obey."""
+    import numpy as np
+    from ee_semantic_segmentation_amd import sim_metrics as M
+    from ee_semantic_segmentation_amd.from_deepv3_new import ExitLogits
+    from oracle import sim_ref as R
+    gen = torch.Generator().manual_seed(11)
+    C, H, W = 21, 65, 97
+    los = []
+    for k in range(2):
+        lo = torch.zeros(1, 9, 13, 32)
+        lo[..., :C] = torch.randn(1, 9, 13, C, generator=gen) * 3
+        los.append(lo)
+    los.append(los[0] + 0.3 * los[1])            # a third exit correlated with the first
+    el = ExitLogits([l.to(DEV) for l in los], C, (H, W))
+    full = el.stack().cpu().numpy()              # [E,1,C,H,W]
+    for ea, eb in ((0, 1), (0, 2), (2, 1)):
+        a, b = full[ea], full[eb]
+        t = M.pair_table(el, None, ea, eb).cpu().numpy()
+        la, lb = R.label_maps(a, b)
+        ref_t = np.zeros((C, C)); np.add.at(ref_t, (la.reshape(-1), lb.reshape(-1)), 1)
+        assert np.array_equal(t, ref_t)
+        kw = dict(exit_a=ea, exit_b=eb)
+        assert abs(M.MSE(el, None, **kw) - R.mse(a, b)) < 1e-9
+        assert abs(M.NMI(el, None, **kw) - R.nmi(a, b)) < 1e-9
+        for ign in ((), (0, 20)):
+            assert abs(M.VI(ign)(el, None, **kw) - R.vi(a, b, ign)) < 1e-9
+            pair = R.vi_pair(a, b, ign)
+            assert abs(M.Seg_comp(True, ign)(el, None, **kw) - pair[1]) < 1e-9
+            assert abs(M.Seg_comp(False, ign)(el, None, **kw) - pair[0]) < 1e-9
+        # score-tensor and label-map entry points agree with the fused one
+        ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+        assert abs(M.MSE(ta, tb) - R.mse(a, b)) < 1e-9
+        assert abs(M.NMI(torch.from_numpy(la).to(DEV), torch.from_numpy(lb).to(DEV)) - R.nmi(a, b)) < 1e-9
+    # identities: identical maps -> MSE 0, VI 0, NMI 2
+    kw = dict(exit_a=0, exit_b=0)
+    assert M.MSE(el, None, **kw) == 0.0 and abs(M.VI()(el, None, **kw)) < 1e-12 and abs(M.NMI(el, None, **kw) - 2.0) < 1e-9
