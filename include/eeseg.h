@@ -263,6 +263,25 @@ int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int H
 int eeseg_sgd_step(void* const* param_grad_buf /*[n][3]*/, const int64_t* sizes, const float* lrs, int n,
                    float momentum, float weight_decay, float grad_scale, int first_step, void* stream);
 
+/* ------------------------------------------------ input pipeline ------- */
+/* The torchvision chain of get_seg_datasets.py:49-86 on decoded uint8 pixels, bit-exact with Pillow:
+ *   image : Resize (PIL bilinear, antialiased; 8-bit intermediate between the passes) -> CenterCrop -> ToTensor ->
+ *           Normalize(mean, std) -> out [C][Dh][Dw] fp32
+ *   target: Resize (PIL forces NEAREST on palette images) -> CenterCrop -> lut[value] -> out [Dh][Dw] int64
+ *           (lut = the reference's ToTensor()*255 -> long -> 255 -> void chain applied to 0..255 on the host).
+ * The two host helpers reproduce Pillow's tables (Resample.c precompute_coeffs/normalize_coeffs_8bpc; Geometry.c
+ * ImagingScaleAffine nearest coordinates, accumulated in double); they do not touch the GPU.
+ * eeseg_pil_bilinear_coeffs returns the tap count ksize (call with NULL tables to size them; kk rows have
+ * `ksize_capacity` entries, which is also the `*ksize` the device call takes). */
+int eeseg_pil_bilinear_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int ksize_capacity);
+int eeseg_pil_nearest_index(int in_size, int out_size, int32_t* idx);
+int eeseg_preprocess_image_u8(const uint8_t* src, int H, int W, int C, int Hr, int Wr, const int32_t* hbounds,
+                              const int32_t* hkk, int hksize, const int32_t* vbounds, const int32_t* vkk, int vksize,
+                              int crop_top, int crop_left, int Dh, int Dw, const float* mean, const float* stdv,
+                              uint8_t* tmp /* [H][Wr][C] */, float* out, void* stream);
+int eeseg_preprocess_label_u8(const uint8_t* src, int H, int W, const int32_t* yidx, const int32_t* xidx, int Hr, int Wr,
+                              int crop_top, int crop_left, int Dh, int Dw, const int64_t* lut, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
