@@ -84,6 +84,8 @@ SIGNATURES = {
     "eeseg_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp,
                                        _vp, _vp, _vp]),
     "eeseg_preprocess_label_u8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "eeseg_argmax_pair_hist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),

@@ -1,5 +1,12 @@
-"""``LovaszSoftmax`` - the reference's multi-exit Lovasz wrapper
-(branchy_seg_losses.py:133-159) on the HIP Lovasz kernels (sort + scan on device).
+"""The reference's multi-exit segmentation losses (branchy_seg_losses.py) on HIP kernels.
+
+``LovaszSoftmax`` (:133-159) runs on the Lovasz kernels (sort + scan on device).  ``DiceLoss`` (:40-48),
+``JaccardLoss`` (:50-78), ``TverskyLoss`` / ``FocalTverskyLoss`` (:80-111) and ``FocalLoss`` (:113-131) share one
+fused pass per exit (``eeseg_class_sums_fwd/bwd``): softmax of the bilinearly upsampled logits is reduced on the
+fly to per-image, per-class sums (and the focal sum), the closed forms on those few numbers are ordinary torch ops
+(autograd differentiates them), and the backward kernel turns dL/dS, dL/dI, dL/dF into low-res logit gradients.
+
+Notes on LovaszSoftmax:
 
 Faithful quirks: the exits' RAW LOGITS are fed to the Lovasz extension (SURVEY F6 /
 B-4: the reference never applies a softmax), per_image=False ranks all pixels of the
@@ -68,3 +75,185 @@ class LovaszSoftmax(nn.Module):
         if self.prev_out:
             return torch.dot(self.weights.to(losses.device), losses).sum()
         return losses.sum()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# region / focal losses (branchy_seg_losses.py:9-131)
+# --------------------------------------------------------------------------------------------------------------
+from . import engine as E  # noqa: E402
+
+
+class _ClassSums(torch.autograd.Function):
+    """(S, I, T, void, F) of one exit from its low-res logits; differentiable in S, I, F."""
+
+    @staticmethod
+    def forward(ctx, lr, target, C, H, W, gamma, alpha):
+        lr = lr.contiguous()
+        sums, extra = K.class_sums_fwd(lr.detach(), C, target, H, W, gamma, alpha)
+        ctx.save_for_backward(lr, target, alpha if alpha is not None else torch.empty(0, device=lr.device))
+        ctx.meta = (C, H, W, gamma, alpha is not None)
+        S, I, T = sums[:, 0, :C].float(), sums[:, 1, :C].float(), sums[:, 2, :C].float()
+        ctx.mark_non_differentiable(T)
+        void, F = extra[:, 0].float(), extra[:, 1].float()
+        ctx.mark_non_differentiable(void)
+        return S, I, T, void, F
+
+    @staticmethod
+    def backward(ctx, gS, gI, _gT, _gV, gF):
+        lr, target, alpha = ctx.saved_tensors
+        C, H, W, gamma, has_alpha = ctx.meta
+        N = lr.shape[0]
+
+        def pad(g):
+            if g is None:
+                return None
+            out = torch.zeros((N, 32), dtype=torch.float32, device=lr.device)
+            out[:, :C] = g
+            return out
+
+        gf = None
+        if gF is not None and gamma >= 0:
+            # the same dL/dF for every image only if it was reduced by a plain sum/mean: pass the per-image factor
+            gf = gF.float().contiguous()
+        dlr = torch.zeros_like(lr)
+        if gf is None or N == 1 or bool((gf == gf[0]).all()):
+            K.class_sums_bwd(lr, C, target, H, W, pad(gS), pad(gI), None if gf is None else gf[:1].contiguous(), dlr, gamma,
+                             alpha if has_alpha else None)
+        else:                       # image-dependent focal weights: one launch per image
+            K.class_sums_bwd(lr, C, target, H, W, pad(gS), pad(gI), None, dlr, gamma, alpha if has_alpha else None)
+            for n in range(N):
+                K.class_sums_bwd(lr[n:n + 1], C, target[n:n + 1], H, W, None, None, gf[n:n + 1].contiguous(), dlr[n:n + 1],
+                                 gamma, alpha if has_alpha else None)
+        return dlr, None, None, None, None, None, None
+
+
+def _exit_lowres(y_pred, i):
+    """-> (low-res logits [N,h,w,32] (autograd-connected), C, (H, W)) of exit i."""
+    if isinstance(y_pred, ExitLogits):
+        return y_pred.lowres[i], y_pred.num_classes, y_pred.size
+    y = y_pred[i]
+    N, C, H, W = y.shape
+    lr = torch.zeros((N, H, W, E.CPAD), dtype=torch.float32, device=y.device)
+    lr[..., :C] = y.permute(0, 2, 3, 1)
+    return lr, C, (H, W)
+
+
+def _targets(targets):
+    if targets.dim() > 3:
+        targets = targets.squeeze(1)
+    return targets.contiguous().long()
+
+
+class BrSegLoss(nn.Module):
+    """branchy_seg_losses.py:9-38: per-exit `_compute_loss`, reduced over everything but the exit axis
+    ('mean' / 'sum' / anything else = no reduction), then dotted with the per-exit weights."""
+
+    def __init__(self, smooth=1e-6, reduction="mean", n_branches=0, weights=None):
+        super().__init__()
+        self.smooth, self.reduction = smooth, reduction
+        self.n = n_branches + 1
+        if weights and len(weights) == n_branches + 1:
+            self.weights = torch.tensor(weights, dtype=torch.float32, requires_grad=True)
+        else:
+            self.weights = torch.ones(self.n, requires_grad=True)
+
+    def update_n(self, n):
+        self.n = n + 1
+
+    def _sums(self, y_pred, i, targets, gamma=-1.0, alpha=None, allow_void=False):
+        lr, C, (H, W) = _exit_lowres(y_pred, i)
+        S, I, T, void, F = _ClassSums.apply(lr, targets, C, H, W, gamma, alpha)
+        if not allow_void and float(void.sum()) > 0:
+            # the reference one-hot encodes / gathers with num_classes = C and fails the same way on a void label
+            raise RuntimeError("Class values must be smaller than num_classes.")
+        return S, I, T, F, C, H * W
+
+    def forward(self, y_pred, targets):
+        targets = _targets(targets)
+        losses = torch.cat([self._compute_loss(y_pred, i, targets).unsqueeze(0) for i in range(self.n)])
+        dim = list(range(1, losses.dim()))
+        if self.reduction == "mean":
+            losses = losses.mean(dim=dim)
+        elif self.reduction == "sum":
+            losses = losses.sum(dim=dim)
+        else:
+            return losses
+        return torch.dot(self.weights.to(device=losses.device), losses)
+
+
+class DiceLoss(BrSegLoss):
+    def _compute_loss(self, y_pred, i, targets):           # :40-48 -> [N]
+        S, I, T, _, _, _ = self._sums(y_pred, i, targets)
+        num = 2 * I.sum(dim=1) + self.smooth
+        den = (S + T).sum(dim=1) + self.smooth
+        return 1 - num / den
+
+
+class JaccardLoss(BrSegLoss):
+    def __init__(self, smooth=1e-6, reduction="mean", n_branches=0, downgrad_bg=1.):
+        super().__init__(smooth, reduction, n_branches)
+        self.downgrad_bg = downgrad_bg if 0 <= downgrad_bg <= 1. else 1.
+
+    def _compute_loss(self, y_pred, i, targets):           # :55-78 -> [N,C] (or [N] when downgrad_bg == 0)
+        S, I, T, _, _, _ = self._sums(y_pred, i, targets, allow_void=True)    # the void one-hot column is dropped
+        union = (S + T) - I
+        IoU = (I + self.smooth) / (union + self.smooth)
+        if self.downgrad_bg:
+            loss = 1 - IoU
+            scale = torch.ones_like(loss)
+            scale[:, 0] = self.downgrad_bg
+            return loss * scale
+        return (1 - IoU).sum(dim=-1)
+
+
+class TverskyLoss(BrSegLoss):
+    """:80-100.  Built on the ARGMAX of the probabilities, so it is piecewise constant: like the reference it
+    yields no gradient for the network (only for the per-exit weights)."""
+
+    def __init__(self, smooth=1e-6, alpha=.5, beta=.5, reduction="mean", n_branches=1, weights=None):
+        super().__init__(smooth, reduction, n_branches, weights)
+        self.alpha, self.beta = alpha, beta
+
+    def _forward_imp(self, y_pred, i, targets):
+        lr, C, (H, W) = _exit_lowres(y_pred, i)
+        lr = lr.detach().contiguous()
+        if int(((targets < 0) | (targets >= C)).sum()) > 0:
+            raise RuntimeError("Class values must be smaller than num_classes.")
+        rows = []
+        for n in range(lr.shape[0]):                       # per-image TP / FP / FN on the fused argmax kernel
+            cnt, _ = K.argmax_confusion(lr[n:n + 1], C, targets[n:n + 1], H, W)
+            rows.append(cnt.float())
+        cnt = torch.stack(rows)                            # [N,3,C]
+        TP, FP, FN = cnt[:, 0], cnt[:, 1], cnt[:, 2]
+        return 1 - (TP + self.smooth) / (TP + self.alpha * FP + self.beta * FN + self.smooth)
+
+    def _compute_loss(self, y_pred, i, targets):
+        return self._forward_imp(y_pred, i, targets)
+
+
+class FocalTverskyLoss(TverskyLoss):
+    def __init__(self, smooth=1e-6, alpha=.5, beta=.5, gamma=1., reduction="mean", n_branches=1, weights=None):
+        super().__init__(smooth, alpha, beta, reduction, n_branches, weights)
+        self.gamma = gamma
+
+    def _compute_loss(self, y_pred, i, targets):
+        return self._forward_imp(y_pred, i, targets) ** self.gamma
+
+
+class FocalLoss(BrSegLoss):
+    """:113-131.  The reference returns the per-pixel map [N,H,W] and reduces it afterwards; the fused kernel
+    reduces on the fly, so only reduction 'mean' / 'sum' are available (the map is never materialised)."""
+
+    def __init__(self, alpha=None, gamma=2, smooth=1e-6, reduction="mean", n_branches=1, weights=None):
+        super().__init__(smooth, reduction, n_branches, weights)
+        if reduction not in ("mean", "sum"):
+            raise NotImplementedError("fused FocalLoss reduces on the fly: reduction must be 'mean' or 'sum'")
+        self.alpha = None if alpha is None else torch.as_tensor(alpha, dtype=torch.float32)
+        self.gamma = gamma
+
+    def _compute_loss(self, y_pred, i, targets):
+        lr = _exit_lowres(y_pred, i)[0]
+        alpha = None if self.alpha is None else self.alpha.to(lr.device).contiguous()
+        _, _, _, F, _, hw = self._sums(y_pred, i, targets, gamma=float(self.gamma), alpha=alpha)
+        # [N] per-image sums; 'mean' over [N,H,W] = sum / (N*H*W): scale so that BrSegLoss.forward's mean over dim 1 fits
+        return F / hw if self.reduction == "mean" else F

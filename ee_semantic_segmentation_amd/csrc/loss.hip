@@ -245,6 +245,170 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------- per-class probability sums (region losses) ----
+// Dice / Jaccard (branchy_seg_losses.py:40-78) are closed forms of three per-image, per-class sums over the
+// full-resolution pixels: S_c = sum p_c, I_c = sum p_c [t = c], T_c = #[t = c] (p = softmax of the upsampled
+// logits); Focal (:113-131) is a per-pixel sum F = sum -alpha_t (1 - p_t)^gamma log p_t.  One pass computes all of
+// them from the low-res logits (same span scheme as the CE kernels).  grid.y = image.
+// sums [N][3][CMAX] double (+=), extra [N][2] double (+=): [0] pixels with a label outside [0,C), [1] F.
+__global__ __launch_bounds__(256) void class_sums_fwd_kernel(const float* __restrict__ lr, int ldc,
+                                                             const int64_t* __restrict__ target, int C, int h, int w,
+                                                             int H, int W, float gamma, const float* __restrict__ alpha,
+                                                             double* sums, double* extra) {
+    __shared__ float red[8][4][32];
+    __shared__ float red2[8][2];
+    const int n = blockIdx.y;
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int total = H * w;
+    const bool active = lane32 < C;
+    float aS = 0.f, aI = 0.f, aT = 0.f, aV = 0.f, aF = 0.f;
+    for (int it = blockIdx.x * 8 + half; it < total; it += gridDim.x * 8) {
+        const int x0 = it % w, y = it / w;
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        const int x1 = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + x1) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + x1) * ldc];
+        }
+        const int64_t* trow = target + ((long long)n * H + y) * W;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;
+            const long long tg = trow[x];
+            const bool labelled = tg >= 0 && tg < C;
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float ssum = half_sum(e);
+            const float pr = e / ssum;
+            aS += pr;
+            if (labelled) {
+                const bool mine = lane32 == (int)tg;
+                aI += mine ? pr : 0.f;
+                aT += mine ? 1.f : 0.f;
+                if (gamma >= 0.f) {                                   // focal term (uniform over the half wave)
+                    const float zt = __shfl(z, (int)tg, 32);
+                    const float logq = zt - (m + __logf(ssum));
+                    const float q = __expf(logq);
+                    const float a = alpha ? alpha[(int)tg] : 1.f;
+                    aF += -a * __powf(fmaxf(1.f - q, 0.f), gamma) * logq;
+                }
+            } else {
+                aV += 1.f;
+            }
+        }
+    }
+    red[half][0][lane32] = aS; red[half][1][lane32] = aI; red[half][2][lane32] = aT;
+    if (lane32 == 0) { red2[half][0] = aV; red2[half][1] = aF; }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int k = threadIdx.x >> 5, c = threadIdx.x & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += (double)red[i][k][c];
+        if (c < C && t != 0.0) atomicAdd(&sums[((size_t)n * 3 + k) * CMAX + c], t);
+    } else if (threadIdx.x < 98) {
+        const int k = threadIdx.x - 96;
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += (double)red2[i][k];
+        if (t != 0.0) atomicAdd(&extra[n * 2 + k], t);
+    }
+}
+
+// Backward of the above: dL/dz_c = p_c (g_c - sum_k p_k g_k), g_c = gS[n][c] + [t = c] gI[n][c], plus the focal
+// term gF a_t [gamma (1-q)^(gamma-1) q log q - (1-q)^gamma] ([c = t] - p_c); transposed interpolation as in the CE
+// backward (span reduction in registers, 128-byte float atomics).
+__global__ __launch_bounds__(256) void class_sums_bwd_kernel(const float* __restrict__ lr, int ldc,
+                                                             const int64_t* __restrict__ target, int C, int h, int w,
+                                                             int H, int W, const float* __restrict__ gS,
+                                                             const float* __restrict__ gI, const float* __restrict__ gF,
+                                                             float gamma, const float* __restrict__ alpha, float* dlr) {
+    const int n = blockIdx.y;
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const bool active = lane32 < C;
+    const float gs = (gS && active) ? gS[n * CMAX + lane32] : 0.f;
+    const float gi = (gI && active) ? gI[n * CMAX + lane32] : 0.f;
+    const float gf = gF ? gF[0] : 0.f;
+    const int total = H * w;
+    for (int it = blockIdx.x * 8 + half; it < total; it += gridDim.x * 8) {
+        const int x0 = it % w, y = it / w;
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        const int xn = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + xn) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + xn) * ldc];
+        }
+        float a0 = 0.f, a1 = 0.f;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;
+            const long long tg = target[((long long)n * H + y) * W + x];
+            const bool labelled = tg >= 0 && tg < C;
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float s = half_sum(e);
+            const float pr = e / s;
+            const bool mine = labelled && lane32 == (int)tg;
+            const float g = gs + (mine ? gi : 0.f);
+            const float dot = half_sum(pr * g);
+            float r = pr * (g - dot);
+            if (gf != 0.f && labelled) {
+                const float zt = __shfl(z, (int)tg, 32);
+                const float logq = zt - (m + __logf(s));
+                const float q = __expf(logq);
+                const float omq = fmaxf(1.f - q, 0.f);
+                const float a = alpha ? alpha[(int)tg] : 1.f;
+                const float k = gamma == 0.f ? -1.f : gamma * __powf(omq, gamma - 1.f) * q * logq - __powf(omq, gamma);
+                r += gf * a * k * ((mine ? 1.f : 0.f) - pr);
+            }
+            if (sx.i1 == sx.i0) {
+                a0 += r;
+            } else {
+                a0 += sx.l0 * r;
+                a1 += sx.l1 * r;
+            }
+        }
+        if (!active) continue;
+        const int x1 = min(x0 + 1, w - 1);
+        float* r0 = dlr + (((size_t)n * h + sy.i0) * w) * ldc + lane32;
+        float* r1 = dlr + (((size_t)n * h + sy.i1) * w) * ldc + lane32;
+        const float wy0 = (sy.i1 == sy.i0) ? 1.f : sy.l0;
+        const float wy1 = (sy.i1 == sy.i0) ? 0.f : sy.l1;
+        if (a0 != 0.f) {
+            atomicAdd(r0 + (size_t)x0 * ldc, wy0 * a0);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x0 * ldc, wy1 * a0);
+        }
+        if (a1 != 0.f) {
+            atomicAdd(r0 + (size_t)x1 * ldc, wy0 * a1);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x1 * ldc, wy1 * a1);
+        }
+    }
+}
+
 // ------------------------------------------------- argmax + TP/FP/FN counts ----
 __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ lr, int ldc,
                                                                const int64_t* __restrict__ target, int N, int C, int h,
@@ -470,6 +634,31 @@ extern "C" int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int
     EESEG_CHECK((counts && target) || pred, EESEG_ERR_ARG, "argmax_confusion: nothing to compute");
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
                        logits_lr, ldc, target, N, C, h, w, H, W, (int*)counts, pred);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_class_sums_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H,
+                                    int W, float gamma, const float* alpha, double* sums, double* extra, void* stream) {
+    CHECK_LR("class_sums_fwd");
+    EESEG_CHECK(target && sums && extra, EESEG_ERR_ARG, "class_sums_fwd: null pointer");
+    long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(class_sums_fwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc,
+                       target, C, h, w, H, W, gamma, alpha, sums, extra);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H,
+                                    int W, const float* gS, const float* gI, const float* gF, float gamma,
+                                    const float* alpha, float* dlogits_lr, void* stream) {
+    CHECK_LR("class_sums_bwd");
+    EESEG_CHECK(target && dlogits_lr && (gS || gI || gF), EESEG_ERR_ARG, "class_sums_bwd: null pointer");
+    long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(class_sums_bwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc,
+                       target, C, h, w, H, W, gS, gI, gF, gamma, alpha, dlogits_lr);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -517,6 +517,28 @@ def argmax_confusion(lr, C_, target, H, W, counts=None, want_pred=False):
     return counts, pred
 
 
+def class_sums_fwd(lr, C_, target, H, W, gamma=-1.0, alpha=None):
+    """-> (sums [N,3,32] float64: S, I, T per image and class;  extra [N,2] float64: void pixels, focal sum)."""
+    N, h, w, ldc = _lr_dims(lr)
+    assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
+    sums = torch.zeros((N, 3, 32), dtype=torch.float64, device=lr.device)
+    extra = torch.zeros((N, 2), dtype=torch.float64, device=lr.device)
+    check(lib().eeseg_class_sums_fwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, float(gamma), _p(alpha), _p(sums),
+                                     _p(extra), _stream()), "eeseg_class_sums_fwd")
+    return sums, extra
+
+
+def class_sums_bwd(lr, C_, target, H, W, gS, gI, gF, dlr, gamma=-1.0, alpha=None):
+    """dlr += backward of class_sums_fwd; gS / gI [N,32] fp32, gF [1] fp32 (device tensors or None)."""
+    N, h, w, ldc = _lr_dims(lr)
+    for g in (gS, gI):
+        assert g is None or (g.shape == (N, 32) and g.dtype == torch.float32 and g.is_contiguous())
+    assert dlr.shape == lr.shape and dlr.is_contiguous()
+    check(lib().eeseg_class_sums_bwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, _p(gS), _p(gI), _p(gF), float(gamma),
+                                     _p(alpha), _p(dlr), _stream()), "eeseg_class_sums_bwd")
+    return dlr
+
+
 def argmax_pair_hist(lr_a, lr_b, C_, H, W, hist=None):
     """Per-image contingency table [N,C,C] int32 of the upsampled argmax maps of two exits."""
     N, h, w, ldc = _lr_dims(lr_a)

@@ -226,6 +226,17 @@ int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int64_t* target
  * mask [N,H,W] int64; target may be NULL when only pred is wanted. */
 int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w,
                            int H, int W, int32_t* counts, int64_t* pred, void* stream);
+/* Region / focal losses (branchy_seg_losses.py:40-131) from low-res logits in one pass per exit: per image and class
+ * S = sum p_c, I = sum p_c [t = c], T = #[t = c] over the full-resolution pixels (p = softmax of the upsampled
+ * logits) -> sums [N][3][32] double (+=); extra [N][2] double (+=): [0] = pixels labelled outside [0,C),
+ * [1] = focal sum  sum -alpha_t (1 - p_t)^gamma log p_t  (gamma < 0: skipped; alpha may be NULL).  Dice / Jaccard are
+ * closed forms of (S, I, T) evaluated by the caller.  The backward takes dL/dS = gS [N][32], dL/dI = gI [N][32]
+ * and dL/dF = gF[0] as DEVICE pointers (any may be NULL) and accumulates (+=) into dlogits_lr. */
+int eeseg_class_sums_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                         float gamma, const float* alpha, double* sums, double* extra, void* stream);
+int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                         const float* gS, const float* gI, const float* gF, float gamma, const float* alpha,
+                         float* dlogits_lr, void* stream);
 /* Fused upsample + argmax of TWO exits -> per-image contingency table hist[N][C][C] int32 (+= per call):
  * hist[n][a][b] = pixels where exit A predicts a and exit B predicts b.  The similarity gates between consecutive
  * exits (MSE / NMI / variation of information of the label maps: sim_metrics.py:41-120, eval_br_sim.py:41-48,

@@ -114,6 +114,36 @@ def main():
                         expected=np.array([c[2] for c in cases], dtype=np.float64))
     print("img_mIoU", [round(c[2], 9) for c in cases])
 
+    # ---- region / focal losses (branchy_seg_losses.py:40-131): value + gradient w.r.t. the scores ----
+    out = {}
+    for k, (seed, E, B, C, H, W) in enumerate([(20, 2, 2, 21, 9, 11), (21, 3, 1, 5, 16, 12), (22, 2, 3, 19, 8, 8)]):
+        torch.manual_seed(seed)
+        y = torch.randn(E, B, C, H, W) * 2
+        t_clean = torch.randint(0, C, [B, 1, H, W])
+        t_void = t_clean.clone()
+        t_void[torch.rand(B, 1, H, W) < 0.15] = C
+        out[f"y{k}"], out[f"t{k}"], out[f"tv{k}"] = y.numpy(), t_clean.numpy(), t_void.numpy()
+        alpha = torch.linspace(0.5, 1.5, C)
+        specs = {
+            "dice_mean": (RBSL.DiceLoss(reduction="mean", n_branches=E - 1), t_clean),
+            "dice_sum": (RBSL.DiceLoss(reduction="sum", n_branches=E - 1, weights=[0.5 + i for i in range(E)]), t_clean),
+            "jaccard_mean": (RBSL.JaccardLoss(reduction="mean", n_branches=E - 1, downgrad_bg=0.3), t_void),
+            "jaccard_sum0": (RBSL.JaccardLoss(reduction="sum", n_branches=E - 1, downgrad_bg=0.0), t_void),
+            "tversky": (RBSL.TverskyLoss(alpha=.3, beta=.7, reduction="mean", n_branches=E - 1), t_clean),
+            "focal_tversky": (RBSL.FocalTverskyLoss(alpha=.3, beta=.7, gamma=1.5, reduction="sum", n_branches=E - 1), t_clean),
+            "focal_mean": (RBSL.FocalLoss(gamma=2, reduction="mean", n_branches=E - 1), t_clean),
+            "focal_sum_alpha": (RBSL.FocalLoss(alpha=alpha, gamma=1.5, reduction="sum", n_branches=E - 1), t_clean),
+        }
+        for name, (crit, t) in specs.items():
+            yy = y.clone().requires_grad_(True)
+            l = crit(yy, t)
+            l.backward()
+            out[f"{name}{k}"] = l.detach().numpy()
+            out[f"{name}{k}_grad"] = np.zeros_like(y.numpy()) if yy.grad is None else yy.grad.numpy()
+    out["alpha_lo_hi"] = np.array([0.5, 1.5])
+    np.savez_compressed(os.path.join(OUT, "region_losses.npz"), **out)
+    print("region losses", {k: float(v) for k, v in out.items() if k.endswith("0") and not k.startswith(("y", "t"))})
+
 
 if __name__ == "__main__":
     main()

@@ -603,3 +603,73 @@ def test_similarity_gates_from_pair_histogram():
     # identities: identical maps -> MSE 0, VI 0, NMI 2
     kw = dict(exit_a=0, exit_b=0)
     assert M.MSE(el, None, **kw) == 0.0 and abs(M.VI()(el, None, **kw)) < 1e-12 and abs(M.NMI(el, None, **kw) - 2.0) < 1e-9
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_region_and_focal_losses_match_reference_vectors(k):
+    """Dice / Jaccard / Tversky / FocalTversky / Focal on the fused class-sums kernels vs values and gradients produced
+    by the reference classes (tests/golden/region_losses.npz), then from LOW-RES exits (upsample fused) vs the oracle."""
+    import os
+    import numpy as np
+    from ee_semantic_segmentation_amd import branchy_seg_losses as B
+    from ee_semantic_segmentation_amd.from_deepv3_new import ExitLogits
+    from oracle import losses_ref as L
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "region_losses.npz"))
+    y = torch.from_numpy(g[f"y{k}"])
+    E, Bn, C = y.shape[0], y.shape[1], y.shape[2]
+    t, tv = torch.from_numpy(g[f"t{k}"]).to(DEV), torch.from_numpy(g[f"tv{k}"]).to(DEV)
+    alpha = torch.linspace(0.5, 1.5, C)
+    specs = {
+        "dice_mean": (B.DiceLoss(reduction="mean", n_branches=E - 1), t),
+        "dice_sum": (B.DiceLoss(reduction="sum", n_branches=E - 1, weights=[0.5 + i for i in range(E)]), t),
+        "jaccard_mean": (B.JaccardLoss(reduction="mean", n_branches=E - 1, downgrad_bg=0.3), tv),
+        "jaccard_sum0": (B.JaccardLoss(reduction="sum", n_branches=E - 1, downgrad_bg=0.0), tv),
+        "tversky": (B.TverskyLoss(alpha=.3, beta=.7, reduction="mean", n_branches=E - 1), t),
+        "focal_tversky": (B.FocalTverskyLoss(alpha=.3, beta=.7, gamma=1.5, reduction="sum", n_branches=E - 1), t),
+        "focal_mean": (B.FocalLoss(gamma=2, reduction="mean", n_branches=E - 1), t),
+    }
+    if Bn == 1:          # with alpha the reference broadcasts across the batch (oracle/losses_ref.br_focal): equal for B = 1
+        specs["focal_sum_alpha"] = (B.FocalLoss(alpha=alpha, gamma=1.5, reduction="sum", n_branches=E - 1), t)
+    for name, (crit, tt) in specs.items():
+        yy = y.clone().to(DEV).requires_grad_(True)
+        l = crit(yy, tt)
+        want = float(g[f"{name}{k}"])
+        assert abs(float(l) - want) <= 2e-5 * max(1.0, abs(want)), (name, float(l), want)
+        l.backward()
+        got = np.zeros_like(g[f"y{k}"]) if yy.grad is None else yy.grad.cpu().numpy()
+        wg = g[f"{name}{k}_grad"]
+        assert np.abs(got - wg).max() <= 2e-4 * max(1e-6, np.abs(wg).max()) + 1e-8, name
+    # void labels: only Jaccard accepts them, the others fail like the reference's one_hot / gather
+    with pytest.raises(RuntimeError):
+        B.DiceLoss(n_branches=E - 1)(y.to(DEV), tv)
+    # low-res exits, upsample fused into the kernels, vs the oracle on the materialised stack
+    gen = torch.Generator().manual_seed(40 + k)
+    H, W = 33, 41
+    los = []
+    for _ in range(2):
+        lo = torch.zeros(2, 5, 6, 32)
+        lo[..., :C] = torch.randn(2, 5, 6, C, generator=gen) * 2
+        los.append(lo.to(DEV).requires_grad_(True))
+    el = ExitLogits(los, C, (H, W))
+    tt = torch.randint(0, C, (2, 1, H, W), generator=gen)
+    stack = el.stack().detach().cpu()
+    pairs = [(B.DiceLoss(n_branches=1), L.br_dice(stack, tt, 2)),
+             (B.JaccardLoss(n_branches=1, downgrad_bg=0.5), L.br_jaccard(stack, tt, 2, downgrad_bg=0.5)),
+             (B.FocalLoss(alpha=alpha, gamma=2, n_branches=1), L.br_focal(stack, tt, 2, alpha=alpha, gamma=2, faithful_alpha=False))]
+    for crit, want in pairs:
+        l = crit(el, tt.to(DEV))
+        assert abs(float(l) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), (type(crit).__name__, float(l), float(want))
+        for lo in los:
+            lo.grad = None
+        l.backward()
+        assert all(lo.grad is not None and torch.isfinite(lo.grad).all() and float(lo.grad.abs().sum()) > 0 for lo in los)
+        # the low-res gradient (softmax Jacobian + transposed interpolation) against a central difference
+        g_an = float(los[1].grad[1, 2, 3, 1])
+        with torch.no_grad():
+            vals = []
+            for eps in (1e-2, -1e-2):
+                los[1][1, 2, 3, 1] += eps
+                vals.append(float(crit(el, tt.to(DEV))))
+                los[1][1, 2, 3, 1] -= eps
+        g_fd = (vals[0] - vals[1]) / 2e-2
+        assert abs(g_an - g_fd) <= 3e-2 * max(abs(g_fd), 1e-4), (type(crit).__name__, g_an, g_fd)

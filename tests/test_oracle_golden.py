@@ -89,3 +89,42 @@ def test_img_miou_oracle_matches_reference_vectors(golden_dir):
         for y, t in zip(g[f"y{i}"], g[f"t{i}"]):
             m(y[None], t[None])
         assert abs(m.compute() - want) < 1e-6, (i, m.compute(), want)
+
+
+def _region_cases(g, k):
+    import torch
+    from oracle import losses_ref as L
+    y = torch.from_numpy(g[f"y{k}"])
+    E, C = y.shape[0], y.shape[2]
+    t, tv = torch.from_numpy(g[f"t{k}"]), torch.from_numpy(g[f"tv{k}"])
+    alpha = torch.linspace(0.5, 1.5, C)
+    return y, {
+        "dice_mean": lambda yy: L.br_dice(yy, t, E, reduction="mean"),
+        "dice_sum": lambda yy: L.br_dice(yy, t, E, reduction="sum", weights=[0.5 + i for i in range(E)]),
+        "jaccard_mean": lambda yy: L.br_jaccard(yy, tv, E, reduction="mean", downgrad_bg=0.3),
+        "jaccard_sum0": lambda yy: L.br_jaccard(yy, tv, E, reduction="sum", downgrad_bg=0.0),
+        "tversky": lambda yy: L.br_tversky(yy, t, E, alpha=.3, beta=.7, reduction="mean"),
+        "focal_tversky": lambda yy: L.br_tversky(yy, t, E, alpha=.3, beta=.7, gamma=1.5, reduction="sum"),
+        "focal_mean": lambda yy: L.br_focal(yy, t, E, gamma=2, reduction="mean"),
+        "focal_sum_alpha": lambda yy: L.br_focal(yy, t, E, alpha=alpha, gamma=1.5, reduction="sum"),
+    }
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_region_and_focal_losses_oracle_matches_reference_vectors(golden_dir, k):
+    """Dice / Jaccard / Tversky / FocalTversky / Focal (branchy_seg_losses.py:40-131): values and gradients produced
+    by the reference classes (scripts/make_golden.py) vs the torch restatement in oracle/losses_ref.py."""
+    g = np.load(os.path.join(golden_dir, "region_losses.npz"))
+    y, cases = _region_cases(g, k)
+    for name, fn in cases.items():
+        yy = y.clone().requires_grad_(True)
+        l = fn(yy)
+        want = float(g[f"{name}{k}"])
+        assert abs(float(l) - want) <= 1e-5 * max(1.0, abs(want)), (name, float(l), want)
+        if l.requires_grad:
+            l.backward()
+            got = yy.grad.numpy()
+        else:
+            got = np.zeros_like(y.numpy())
+        wg = g[f"{name}{k}_grad"]
+        assert np.abs(got - wg).max() <= 1e-5 * max(1e-6, np.abs(wg).max()) + 1e-9, name
