@@ -663,13 +663,16 @@ def test_region_and_focal_losses_match_reference_vectors(k):
             lo.grad = None
         l.backward()
         assert all(lo.grad is not None and torch.isfinite(lo.grad).all() and float(lo.grad.abs().sum()) > 0 for lo in los)
-        # the low-res gradient (softmax Jacobian + transposed interpolation) against a central difference
-        g_an = float(los[1].grad[1, 2, 3, 1])
+        # the low-res gradient (softmax Jacobian + transposed interpolation) against a central difference along
+        # sign(grad) of the second exit, the direction in which the first-order change is largest
+        d = torch.sign(los[1].grad)
+        first_order = float((los[1].grad * d).sum())
+        eps = 2e-2
         with torch.no_grad():
             vals = []
-            for eps in (1e-2, -1e-2):
-                los[1][1, 2, 3, 1] += eps
+            for sgn in (1.0, -1.0):
+                los[1] += sgn * eps * d
                 vals.append(float(crit(el, tt.to(DEV))))
-                los[1][1, 2, 3, 1] -= eps
-        g_fd = (vals[0] - vals[1]) / 2e-2
-        assert abs(g_an - g_fd) <= 3e-2 * max(abs(g_fd), 1e-4), (type(crit).__name__, g_an, g_fd)
+                los[1] -= sgn * eps * d
+        g_fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(first_order - g_fd) <= 3e-2 * abs(g_fd) + 1e-5, (type(crit).__name__, first_order, g_fd)
