@@ -985,6 +985,8 @@ int launch(const ConvP& p, hipStream_t st) {
 
 }  // namespace
 
+extern int g_ce_span;     // loss.hip
+
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
         g_conv_pipe = value;
@@ -996,6 +998,10 @@ extern "C" int eeseg_set_option(int key, int value) {
     }
     if (key == EESEG_OPT_CONV_NARROW_MAX && value >= 64 && value <= 4096) {
         g_conv_narrow_max = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CE_SPAN && (value == 0 || value == 1)) {
+        g_ce_span = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_CONV_TAIL_MIN && value >= 0 && value <= 256) {
@@ -1017,6 +1023,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_NARROW_MAX: return g_conv_narrow_max;
         case EESEG_OPT_CONV_AUTO_NARROW: return g_conv_auto_narrow;
         case EESEG_OPT_CONV_TAIL_MIN: return g_conv_big_tail_min;
+        case EESEG_OPT_CE_SPAN: return g_ce_span;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;

@@ -9,6 +9,8 @@
 // are 128-byte coalesced loads and softmax / argmax are half-wave DPP reductions.
 #include "eeseg_common.h"
 
+int g_ce_span = 1;        // EESEG_OPT_CE_SPAN: 1 = thread-per-span cross-entropy kernels (default), 0 = half-wave-per-pixel
+
 namespace {
 
 constexpr int CMAX = 32;
@@ -242,6 +244,194 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(const float* __res
             atomicAdd(r0 + (size_t)x1 * ldc, g * wy0 * a1);
             if (wy1 != 0.f) atomicAdd(r1 + (size_t)x1 * ldc, g * wy1 * a1);
         }
+    }
+}
+
+// ------------------------------------------ cross entropy, one THREAD per span ----
+// The half-wave-per-pixel kernels above spend ~2/3 of their instructions in the two 32-lane reductions of every
+// pixel.  Here a thread owns one span (row y, source column x0: ~H/h pixels that share the same four low-res
+// vectors): the y-interpolated vectors P = l0y*v[y0][x0] + l1y*v[y1][x0] and Q (column x0+1) live in registers,
+// every pixel is z_c = l0x*P_c + l1x*Q_c and its softmax statistics are plain loops over the classes - no
+// cross-lane traffic at all (5-6x fewer wave instructions).  Classes beyond C carry -1e30 (exp -> 0, never NaN).
+template <int CP>
+__device__ __forceinline__ void span_vectors(const float* __restrict__ lr, int ldc, int w, int C, int n, int h, const Src& sy,
+                                             int x0, float (&P)[CP], float (&Q)[CP]) {
+    const int x1 = min(x0 + 1, w - 1);
+    const float* r0 = lr + ((size_t)n * h + sy.i0) * w * ldc;
+    const float* r1 = lr + ((size_t)n * h + sy.i1) * w * ldc;
+#pragma unroll
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(r0 + (size_t)x0 * ldc + 4 * c4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(r1 + (size_t)x0 * ldc + 4 * c4);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(r0 + (size_t)x1 * ldc + 4 * c4);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(r1 + (size_t)x1 * ldc + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = 4 * c4 + k < C;
+            P[4 * c4 + k] = ok ? sy.l0 * a[k] + sy.l1 * b[k] : -1e30f;
+            Q[4 * c4 + k] = ok ? sy.l0 * a1[k] + sy.l1 * b1[k] : -1e30f;
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(256) void upsample_ce_fwd_span_kernel(const float* __restrict__ lr, int ldc,
+                                                                   const int64_t* __restrict__ target, int N, int C, int h,
+                                                                   int w, int H, int W, long long ignore_index,
+                                                                   double* accum) {
+    __shared__ float sl[4], sc[4];
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const long long total = (long long)N * H * w;
+    float loss_acc = 0.f, cnt_acc = 0.f;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const int x0 = (int)(it % w);
+        const long long t = it / w;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        float P[CP], Q[CP];
+        span_vectors<CP>(lr, ldc, w, C, n, h, sy, x0, P, Q);
+        const int64_t* trow = target + ((long long)n * H + y) * W;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;
+            const long long tg = trow[x];
+            if (tg == ignore_index || tg < 0 || tg >= C) continue;
+            float z[CP];
+            float m = -INFINITY, zt = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) {
+                z[c] = sx.l0 * P[c] + sx.l1 * Q[c];
+                m = fmaxf(m, z[c]);
+                zt = (c == (int)tg) ? z[c] : zt;
+            }
+            float ssum = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) ssum += __expf(z[c] - m);
+            loss_acc += (m + __logf(ssum)) - zt;
+            cnt_acc += 1.f;
+        }
+    }
+    loss_acc = wave_sum(loss_acc);
+    cnt_acc = wave_sum(cnt_acc);
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = loss_acc; sc[threadIdx.x >> 6] = cnt_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double l = (double)sl[0] + (double)sl[1] + (double)sl[2] + (double)sl[3];
+        const double c = (double)sc[0] + (double)sc[1] + (double)sc[2] + (double)sc[3];
+        if (c > 0.0) {
+            atomicAdd(&accum[0], l);
+            atomicAdd(&accum[1], c);
+        }
+    }
+}
+
+// Backward: a block owns 256 consecutive spans of one image (a few output rows).  Every thread reduces its span into
+// the two source columns in registers and parks the 2 x C partial sums in its own LDS slot (plain stores, 49-float
+// stride = conflict free).  Then the block turns around: one thread per (source row, column, class) GATHERS the few
+// slots that feed it (<= 2 per output row of the block) and issues one class-contiguous global atomic.  No LDS atomics
+// (ds_add_f32 measured ~170 cycles per wave instruction here) and ~5x fewer, fully coalesced global float atomics
+// than one flush per span.
+template <int CP>
+__global__ __launch_bounds__(256) void upsample_ce_bwd_span_kernel(const float* __restrict__ lr, int ldc,
+                                                                   const int64_t* __restrict__ target, int C, int h, int w,
+                                                                   int H, int W, long long ignore_index,
+                                                                   const double* __restrict__ accum, float gscale,
+                                                                   const float* __restrict__ gscale_dev, float* dlr,
+                                                                   int tile_rows) {
+    constexpr int SLOT = 2 * CP + 1;
+    extern __shared__ float slots[];                        // [256][SLOT]: a0[CP], a1[CP]
+    const double cnt = accum[1];
+    if (!(cnt > 0.0)) return;
+    const float g = (float)((double)gscale * (gscale_dev ? (double)gscale_dev[0] : 1.0) / cnt);
+    const int n = blockIdx.y;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int items = H * w;
+    const int first = blockIdx.x * 256;
+    const int item = first + threadIdx.x;
+    {
+        float a0[CP], a1[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) { a0[c] = 0.f; a1[c] = 0.f; }
+        if (item < items) {
+            const int x0 = item % w, y = item / w;
+            int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+            int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+            xa = (x0 == 0) ? 0 : max(xa, 0);
+            xb = min(xb, W - 1);
+            const Src sy = src_index(y, sh, h);
+            float P[CP], Q[CP];
+            span_vectors<CP>(lr, ldc, w, C, n, h, sy, x0, P, Q);
+            const int64_t* trow = target + ((long long)n * H + y) * W;
+            for (int x = xa; x <= xb; ++x) {
+                const Src sx = src_index(x, sw, w);
+                if (sx.i0 != x0) continue;
+                const long long tg = trow[x];
+                if (tg == ignore_index || tg < 0 || tg >= C) continue;
+                float e[CP];
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    e[c] = sx.l0 * P[c] + sx.l1 * Q[c];
+                    m = fmaxf(m, e[c]);
+                }
+                float ssum = 0.f;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    e[c] = __expf(e[c] - m);
+                    ssum += e[c];
+                }
+                const float inv = 1.f / ssum;
+                const bool clamp = sx.i1 == sx.i0;          // right border: both taps on x0
+                const float w0 = clamp ? 1.f : sx.l0, w1 = clamp ? 0.f : sx.l1;
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    const float r = e[c] * inv - ((c == (int)tg) ? 1.f : 0.f);
+                    a0[c] += w0 * r;
+                    a1[c] += w1 * r;
+                }
+            }
+        }
+        float* mine = slots + threadIdx.x * SLOT;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            mine[c] = g * a0[c];
+            mine[CP + c] = g * a1[c];
+        }
+    }
+    __syncthreads();
+    // gather: output (source row r, column x, class c) <- spans (y, x)[a0] and (y, x-1)[a1] of the block's rows y
+    const int y_first = first / w;
+    const int y_last = min(H - 1, (first + 255) / w);
+    const int ny = y_last - y_first + 1;
+    const int base_row = src_index(y_first, sh, h).i0;
+    float* wtab = slots + 256 * SLOT;                       // [tile_rows][ny]: y-weight of output row y on source row r
+    for (int i = threadIdx.x; i < tile_rows * ny; i += 256) {
+        const int r = base_row + i / ny;
+        const Src sy = src_index(y_first + i % ny, sh, h);
+        wtab[i] = (sy.i0 == r ? ((sy.i1 == sy.i0) ? 1.f : sy.l0) : 0.f) + ((sy.i1 == r && sy.i1 != sy.i0) ? sy.l1 : 0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tile_rows * w * 32; i += 256) {
+        const int c = i & 31, x = (i >> 5) % w, rl = (i >> 5) / w;
+        if (c >= C || base_row + rl >= h) continue;
+        float v = 0.f;
+        for (int yl = 0; yl < ny; ++yl) {
+            const float wy = wtab[rl * ny + yl];
+            if (wy == 0.f) continue;
+            const int t0 = (y_first + yl) * w + x - first;   // span (y, x): its a0 lands on column x
+            if (t0 >= 0 && t0 < 256) v += wy * slots[t0 * SLOT + c];
+            if (x > 0) {                                     // span (y, x-1): its a1 lands on column x
+                const int t1 = t0 - 1;
+                if (t1 >= 0 && t1 < 256) v += wy * slots[t1 * SLOT + CP + c];
+            }
+            if (x == w - 1 && t0 >= 0 && t0 < 256) v += wy * slots[t0 * SLOT + CP + c];   // clamped right tap (always 0)
+        }
+        if (v != 0.f) atomicAdd(dlr + (((size_t)n * h + base_row + rl) * w + x) * ldc + c, v);
     }
 }
 
@@ -610,6 +800,21 @@ extern "C" int eeseg_upsample_ce_fwd(const float* logits_lr, int ldc, const int6
                                      int H, int W, int64_t ignore_index, double* accum, void* stream) {
     CHECK_LR("upsample_ce_fwd");
     EESEG_CHECK(target && accum && ((uintptr_t)accum & 7) == 0, EESEG_ERR_ARG, "upsample_ce_fwd: bad target/accum");
+    if (g_ce_span && ldc % 4 == 0 && ldc >= ((C + 3) & ~3) && (long long)N * H * w < (1ll << 31)) {   // thread-per-span form
+        const long long items = (long long)N * H * w;
+        const unsigned grid = (unsigned)((items + 255) / 256 > 8192 ? 8192 : (items + 255) / 256);
+        hipStream_t st = (hipStream_t)stream;
+        if (C <= 8)
+            hipLaunchKernelGGL(upsample_ce_fwd_span_kernel<8>, dim3(grid), dim3(256), 0, st, logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
+        else if (C <= 16)
+            hipLaunchKernelGGL(upsample_ce_fwd_span_kernel<16>, dim3(grid), dim3(256), 0, st, logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
+        else if (C <= 24)
+            hipLaunchKernelGGL(upsample_ce_fwd_span_kernel<24>, dim3(grid), dim3(256), 0, st, logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
+        else
+            hipLaunchKernelGGL(upsample_ce_fwd_span_kernel<32>, dim3(grid), dim3(256), 0, st, logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
+        EESEG_LAUNCH_CHECK();
+        return EESEG_OK;
+    }
     hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(px_grid((long long)N * H * w)), dim3(256), 0, (hipStream_t)stream,
                        logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum);
     EESEG_LAUNCH_CHECK();
@@ -621,6 +826,28 @@ extern "C" int eeseg_upsample_ce_bwd(const float* logits_lr, int ldc, const int6
                                      const float* gscale_dev, float* dlogits_lr, void* stream) {
     CHECK_LR("upsample_ce_bwd");
     EESEG_CHECK(target && accum && dlogits_lr, EESEG_ERR_ARG, "upsample_ce_bwd: null pointer");
+    {
+        // source rows a block of 256 consecutive spans can touch: its output rows (256/w + 2) scaled by h/H, + 2 for
+        // the second tap and the rounding of both ends
+        const int out_rows = 256 / w + 2;
+        const int tile_rows = (int)((double)out_rows * (double)h / (double)H) + 3;
+        const int cp = C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 24 ? 24 : 32));
+        const size_t lds = ((size_t)256 * (2 * cp + 1) + (size_t)tile_rows * out_rows) * sizeof(float);
+        if (g_ce_span && ldc % 4 == 0 && ldc >= ((C + 3) & ~3) && lds <= 64 * 1024 && tile_rows * w <= 4096) {
+            const dim3 grid((unsigned)(((long long)H * w + 255) / 256), N);
+            hipStream_t st = (hipStream_t)stream;
+#define EESEG_CE_BWD(CPV)                                                                                                  \
+    hipLaunchKernelGGL(upsample_ce_bwd_span_kernel<CPV>, grid, dim3(256), lds, st, logits_lr, ldc, target, C, h, w, H, W,   \
+                       (long long)ignore_index, accum, gscale, gscale_dev, dlogits_lr, tile_rows)
+            if (C <= 8) EESEG_CE_BWD(8);
+            else if (C <= 16) EESEG_CE_BWD(16);
+            else if (C <= 24) EESEG_CE_BWD(24);
+            else EESEG_CE_BWD(32);
+#undef EESEG_CE_BWD
+            EESEG_LAUNCH_CHECK();
+            return EESEG_OK;
+        }
+    }
     hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3(px_grid((long long)N * H * w)), dim3(256), 0, (hipStream_t)stream,
                        logits_lr, ldc, target, N, C, h, w, H, W, (long long)ignore_index, accum, gscale, gscale_dev,
                        dlogits_lr);

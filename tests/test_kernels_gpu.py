@@ -676,3 +676,34 @@ def test_region_and_focal_losses_match_reference_vectors(k):
                 los[1] -= sgn * eps * d
         g_fd = (vals[0] - vals[1]) / (2 * eps)
         assert abs(first_order - g_fd) <= 3e-2 * abs(g_fd) + 1e-5, (type(crit).__name__, first_order, g_fd)
+
+
+@pytest.mark.parametrize("hw,HW,Cc", [((65, 65), (513, 513), 21), ((97, 97), (769, 769), 19), ((33, 40), (33, 40), 21),
+                                      ((8, 130), (60, 1030), 7)])
+def test_ce_thread_per_span_kernels_match_half_wave_kernels(hw, HW, Cc):
+    """EESEG_OPT_CE_SPAN: the thread-per-span cross-entropy kernels (default) vs the half-wave-per-pixel ones at the
+    training shapes (and a wide map that takes the fallback in the backward: LDS tile too large)."""
+    from ee_semantic_segmentation_amd._lib import lib
+    (h, w), (H, W) = hw, HW
+    N = 2
+    gen = torch.Generator().manual_seed(23)
+    lr = torch.zeros(N, h, w, 32)
+    lr[..., :Cc] = torch.randn(N, h, w, Cc, generator=gen) * 3
+    lr = lr.to(DEV)
+    t = torch.randint(0, Cc + 1, (N, H, W), generator=gen).to(DEV)
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib().eeseg_set_option(6, mode)
+            acc = torch.zeros(2, dtype=torch.float64, device=DEV)
+            K.upsample_ce_fwd(lr, Cc, t, H, W, Cc, acc)
+            dlr = torch.zeros_like(lr)
+            K.upsample_ce_bwd(lr, Cc, t, H, W, Cc, acc, 0.9, dlr)
+            torch.cuda.synchronize()
+            out[mode] = (acc.cpu(), dlr)
+    finally:
+        lib().eeseg_set_option(6, 1)
+    assert out[0][0][1] == out[1][0][1] == float((t != Cc).sum())
+    assert abs(out[0][0][0] - out[1][0][0]) <= 2e-6 * abs(out[0][0][0])
+    close(out[1][1], out[0][1], 2e-5, "ce bwd span vs half-wave")
+    assert out[1][1][..., Cc:].abs().max().item() == 0
