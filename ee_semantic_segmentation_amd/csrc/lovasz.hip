@@ -1,10 +1,11 @@
 // Multi-class Lovasz loss on RAW scores for one exit (branchy_seg_losses.py:154 ->
 // lovaszsoftmax.py:172-200, per_image=False, classes='present'), fully on device:
 //   1. prep : key[c][p] = |1[y_p=c] - s_pc| (valid pixels) or -1 (void: sorts last),
-//             val = pixel index | sign bit;  class pixel counts G[c], #valid pixels
+//             val = pixel index | foreground bit 30 | sign bit 31;  class pixel counts G[c], #valid pixels
 //   2. sort : hand-written segmented LSD radix sort (4 passes of 8 bits, descending, one
 //             segment per class): per-tile LDS histograms -> per-class scan of the
-//             (digit, tile) counts -> stable scatter with wave-ballot digit matching
+//             (digit, tile) counts -> stable scatter: wave-ballot digit matching, tile sorted
+//             locally in LDS, written out as contiguous runs
 //   3. scan : per class, blocked inclusive scan of the sorted foreground flags ->
 //             Jaccard gradient J_k - J_{k-1} (lovasz_grad, lovaszsoftmax.py:19-31),
 //             loss_c = sum e_k * grad_k, and d(loss)/d(score) scattered back through
@@ -39,12 +40,13 @@ __global__ __launch_bounds__(256) void lv_prep(const float* __restrict__ scores,
         const int hw = (int)(p - (long long)n * HW);
         for (int c = 0; c < C; ++c) {
             float key = -1.f;
-            unsigned v = (unsigned)p;
+            unsigned v = (unsigned)p;                       // p < 2^30 (P*C < 2^31, C >= 2): bits 30/31 are free
             if (valid) {
                 const float s = scores[((size_t)n * C + c) * HW + hw];
                 const float d = (t == c ? 1.f : 0.f) - s;
                 key = fabsf(d);
-                if (d < 0.f) v |= 0x80000000u;
+                if (d < 0.f) v |= 0x80000000u;              // sign of (fg - s)
+                if (t == c) v |= 0x40000000u;               // foreground flag travels with the element
             }
             keys[(size_t)c * P + p] = key;
             vals[(size_t)c * P + p] = v;
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(256) void lv_prep(const float* __restrict__ scores,
 // ------------------------------------------------------------------ radix sort ----
 // Keys are floats >= 0 or -1; descending float order == ascending order of
 // ukey = ~(sign-flipped bits).  One pass sorts by 8 bits, least significant first.
-constexpr int RT = 4096;            // elements per sort tile (256 threads x 16)
+constexpr int RT = 8192;            // elements per sort tile (4 waves x 32 rows x 64)
+constexpr int RS_LDS = (2 * RT + 4 * 256 + 256 + 256 + 4) * 4;   // rs_scatter dynamic LDS bytes
 
 __device__ __forceinline__ unsigned sort_key(float f) {
     unsigned u = __float_as_uint(f);
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(256) void rs_hist(const float* __restrict__ keys, l
     hist[((size_t)c * 256 + threadIdx.x) * ntile + t] = sh[threadIdx.x];
 }
 
-// exclusive scan of hist[c][:] (256*ntile entries, digit-major) in place; one block per class
-__global__ __launch_bounds__(1024) void rs_scan(unsigned* hist, int n) {
+// exclusive scan of n consecutive entries per blockIdx.x, in place; optionally stores the total
+__global__ __launch_bounds__(1024) void rs_scan(unsigned* hist, int n, unsigned* totals = nullptr) {
     __shared__ unsigned swave[16];
     __shared__ unsigned carry;
     unsigned* h = hist + (size_t)blockIdx.x * n;
@@ -113,51 +116,101 @@ __global__ __launch_bounds__(1024) void rs_scan(unsigned* hist, int n) {
         if (threadIdx.x == 1023) carry = off + incl;
         __syncthreads();
     }
+    if (totals && threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// stable scatter: element -> hist[c][digit][tile] + (rank among the tile's earlier elements with that digit)
+// Stable scatter of one tile (RT elements) of one class.  Wave w owns the contiguous quarter [w*RT/4, (w+1)*RT/4) of the
+// tile, 64 consecutive elements per row:
+//   A. per wave, row by row: lanes holding the same digit find each other with 8 ballots; rank inside the wave =
+//      (per-wave digit counter so far) + (same-digit lanes below me); the row's first lane of each digit bumps the counter
+//      (LDS operations of one wave execute in order: no barrier inside the loop);
+//   B. per digit: exclusive prefix of the wave counters, tile-local start of the digit (block scan), global start from
+//      the scanned histogram;
+//   C. every element goes to its tile-local sorted position in LDS;
+//   D. the tile is written out in sorted order: a digit's elements are consecutive in LDS AND in global memory, so the
+//      stores are contiguous runs (RT/256 = 32 elements = 128 B on average) instead of one 4-byte transaction each.
 __global__ __launch_bounds__(256) void rs_scatter(const float* __restrict__ kin, const unsigned* __restrict__ vin,
                                                   float* __restrict__ kout, unsigned* __restrict__ vout, long long P,
-                                                  int ntile, int shift, const unsigned* __restrict__ hist) {
-    __shared__ unsigned sbase[256];         // running output position per digit
-    __shared__ unsigned scnt[4][256];       // per-wave digit counts of the current 256-element round
+                                                  int ntile, int shift, const unsigned* __restrict__ hist,
+                                                  const unsigned* __restrict__ dtot) {
+    constexpr int ROWS = RT / 256;              // rows of 64 elements per wave
+    __shared__ unsigned smem_rs[RS_LDS / 4];
+    unsigned* sk = smem_rs;                     // [RT] staged keys (as bits)
+    unsigned* sv = smem_rs + RT;                // [RT] staged values
+    unsigned* cntw = smem_rs + 2 * RT;          // [4][256] per-wave digit counters -> exclusive wave prefixes
+    unsigned* lstart = cntw + 4 * 256;          // [256] tile-local start of each digit
+    unsigned* gbase = lstart + 256;             // [256] global start of each digit for this tile
+    unsigned* swsum = gbase + 256;              // [4] block-scan scratch
     const int c = blockIdx.y, t = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    sbase[threadIdx.x] = hist[((size_t)c * 256 + threadIdx.x) * ntile + t];
-    const long long base = (long long)t * RT;
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) cntw[i] = 0u;
+    __syncthreads();
+    const long long base = (long long)t * RT + (long long)wave * (RT / 4);
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int r = 0; r < RT / 256; ++r) {
+    unsigned key[ROWS], val[ROWS];
+    unsigned short rank[ROWS];
+    unsigned* myc = cntw + wave * 256;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) scnt[w][threadIdx.x] = 0u;
-        __syncthreads();
-        const long long k = base + r * 256 + threadIdx.x;      // wave w owns 64 consecutive elements: stable
+    for (int r = 0; r < ROWS; ++r) {
+        const long long k = base + r * 64 + lane;
         const bool ok = k < P;
-        float key = 0.f;
-        unsigned val = 0u, dg = 0u;
+        unsigned dg = 0u;
+        key[r] = 0u; val[r] = 0u;
         if (ok) {
-            key = kin[(size_t)c * P + k];
-            val = vin[(size_t)c * P + k];
-            dg = (sort_key(key) >> shift) & 255u;
+            key[r] = __float_as_uint(kin[(size_t)c * P + k]);
+            val[r] = vin[(size_t)c * P + k];
+            dg = (sort_key(__uint_as_float(key[r])) >> shift) & 255u;
         }
-        // lanes of this wave holding the same digit (8 ballots), inactive lanes excluded
         unsigned long long same = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const unsigned long long m = __ballot((dg >> b) & 1u);
             same &= ((dg >> b) & 1u) ? m : ~m;
         }
-        const unsigned rank_in_wave = (unsigned)__popcll(same & below);
-        if (ok && rank_in_wave == 0) scnt[wave][dg] = (unsigned)__popcll(same);      // one writer per (wave, digit)
-        __syncthreads();
-        if (ok) {
-            unsigned off = sbase[dg] + rank_in_wave;
-            for (int w = 0; w < wave; ++w) off += scnt[w][dg];
-            kout[(size_t)c * P + off] = key;
-            vout[(size_t)c * P + off] = val;
+        const unsigned in_row = (unsigned)__popcll(same & below);
+        const unsigned prior = ok ? myc[dg] : 0u;
+        rank[r] = (unsigned short)(prior + in_row);
+        if (ok && in_row == 0) myc[dg] = prior + (unsigned)__popcll(same);
+    }
+    __syncthreads();
+    {   // B: thread d = digit
+        const int d = threadIdx.x;
+        const unsigned c0 = cntw[d], c1 = cntw[256 + d], c2 = cntw[512 + d], c3 = cntw[768 + d];
+        cntw[d] = 0u; cntw[256 + d] = c0; cntw[512 + d] = c0 + c1; cntw[768 + d] = c0 + c1 + c2;
+        const unsigned tot = c0 + c1 + c2 + c3;
+        unsigned incl = tot;                    // exclusive scan of tot over the 256 digits
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
         }
+        if (lane == 63) swsum[wave] = incl;
         __syncthreads();
-        sbase[threadIdx.x] += scnt[0][threadIdx.x] + scnt[1][threadIdx.x] + scnt[2][threadIdx.x] + scnt[3][threadIdx.x];
-        __syncthreads();
+        unsigned off = 0u;
+        for (int w = 0; w < wave; ++w) off += swsum[w];
+        lstart[d] = off + incl - tot;
+        gbase[d] = dtot[c * 256 + d] + hist[((size_t)c * 256 + d) * ntile + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {            // C
+        const long long k = base + r * 64 + lane;
+        if (k < P) {
+            const unsigned dg = (sort_key(__uint_as_float(key[r])) >> shift) & 255u;
+            const unsigned lp = lstart[dg] + myc[dg] + rank[r];
+            sk[lp] = key[r];
+            sv[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const long long tile_first = (long long)t * RT;
+    const int n_here = (int)((P - tile_first < RT) ? (P - tile_first) : RT);
+    for (int i = threadIdx.x; i < n_here; i += 256) {          // D
+        const unsigned kb = sk[i];
+        const unsigned dg = (sort_key(__uint_as_float(kb)) >> shift) & 255u;
+        const size_t o = (size_t)c * P + gbase[dg] + ((unsigned)i - lstart[dg]);
+        kout[o] = __uint_as_float(kb);
+        vout[o] = sv[i];
     }
 }
 
@@ -172,7 +225,7 @@ __global__ __launch_bounds__(256) void lv_block_counts(const unsigned* __restric
     int cnt = 0;
     for (int i = threadIdx.x; i < SB; i += 256) {
         const long long k = (long long)b * SB + i;
-        if (k < nv) cnt += (target[vals[(size_t)c * P + k] & 0x7FFFFFFFu] == c) ? 1 : 0;
+        if (k < nv) cnt += (int)((vals[(size_t)c * P + k] >> 30) & 1u);
     }
     cnt = (int)wave_sum((float)cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s, cnt);
@@ -180,18 +233,10 @@ __global__ __launch_bounds__(256) void lv_block_counts(const unsigned* __restric
     if (threadIdx.x == 0) bsum[(size_t)c * nblk + b] = s;
 }
 
-// exclusive scan of the block counts per class (in place) + number of present classes
-__global__ void lv_scan_blocks(int* bsum, int nblk, int C, const int* G, LvHeader* hdr) {
+// number of present classes (the block counts are scanned by rs_scan, one block per class)
+__global__ void lv_count_present(int C, const int* G, LvHeader* hdr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        int run = 0;
-        for (int b = 0; b < nblk; ++b) {
-            const int v = bsum[(size_t)c * nblk + b];
-            bsum[(size_t)c * nblk + b] = run;
-            run += v;
-        }
-        if (G[c] > 0) atomicAdd(&hdr->n_present, 1);
-    }
+    if (c < C && G[c] > 0) atomicAdd(&hdr->n_present, 1);
 }
 
 __device__ __forceinline__ float jaccard(float G, float F, float kp1) {   // 1 - (G-F)/(G + k+1 - F)
@@ -222,7 +267,7 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
         if (k < nv) {
             v[i] = vals[(size_t)c * P + k];
             e[i] = keys[(size_t)c * P + k];
-            fg[i] = (target[v[i] & 0x7FFFFFFFu] == c) ? 1 : 0;
+            fg[i] = (int)((v[i] >> 30) & 1u);
         } else {
             v[i] = 0; e[i] = 0.f; fg[i] = 0;
         }
@@ -253,7 +298,7 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
         const float gr = jk - jprev;
         part += (double)e[i] * (double)gr;
         if (dscores != nullptr) {
-            const unsigned px = v[i] & 0x7FFFFFFFu;
+            const unsigned px = v[i] & 0x3FFFFFFFu;
             const int n = (int)(px / (unsigned)HW);
             const int hw = (int)(px - (unsigned)n * (unsigned)HW);
             // e = |fg - s|  ->  de/ds = -sign(fg - s); sign(0) = 0 like torch.abs
@@ -279,7 +324,7 @@ __global__ void lv_loss(const double* class_loss, const int* G, int C, const LvH
 }
 
 struct Layout {
-    size_t hdr, G, closs, bsum, hist, keys_in, keys_out, vals_in, vals_out, total;
+    size_t hdr, G, closs, bsum, hist, dtot, keys_in, keys_out, vals_in, vals_out, total;
 };
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 Layout layout(long long P, int C) {
@@ -292,6 +337,7 @@ Layout layout(long long P, int C) {
     L.closs = o; o += align256((size_t)C * 8);
     L.bsum = o; o += align256((size_t)C * nblk * 4);
     L.hist = o; o += align256((size_t)C * 256 * ntile * 4);
+    L.dtot = o; o += align256((size_t)C * 256 * 4);
     const size_t arr = align256((size_t)C * P * 4);
     L.keys_in = o; o += arr;
     L.keys_out = o; o += arr;
@@ -323,6 +369,7 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     int* G = (int*)(w + L.G);
     double* closs = (double*)(w + L.closs);
     unsigned* hist = (unsigned*)(w + L.hist);
+    unsigned* dtot = (unsigned*)(w + L.dtot);
     int* bsum = (int*)(w + L.bsum);
     float* keys_in = (float*)(w + L.keys_in);
     float* keys_out = (float*)(w + L.keys_out);
@@ -343,9 +390,12 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     unsigned* va = vals_in; unsigned* vb = vals_out;
     for (int pass = 0; pass < 4; ++pass) {
         hipLaunchKernelGGL(rs_hist, dim3(ntile, C), dim3(256), 0, st, (const float*)ka, P, ntile, pass * 8, hist);
-        hipLaunchKernelGGL(rs_scan, dim3(C), dim3(1024), 0, st, hist, 256 * ntile);
+        // two-level scan: (class, digit) blocks scan their tile counts and emit the digit totals; one block per class
+        // scans the 256 totals; the scatter adds the two
+        hipLaunchKernelGGL(rs_scan, dim3(C * 256), dim3(1024), 0, st, hist, ntile, dtot);
+        hipLaunchKernelGGL(rs_scan, dim3(C), dim3(1024), 0, st, dtot, 256, (unsigned*)nullptr);
         hipLaunchKernelGGL(rs_scatter, dim3(ntile, C), dim3(256), 0, st, (const float*)ka, (const unsigned*)va, kb, vb, P,
-                           ntile, pass * 8, (const unsigned*)hist);
+                           ntile, pass * 8, (const unsigned*)hist, (const unsigned*)dtot);
         float* tk = ka; ka = kb; kb = tk;
         unsigned* tv = va; va = vb; vb = tv;
     }
@@ -353,7 +403,8 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     keys_out = ka;                 // after an even number of passes the sorted data is back in the first pair
     vals_out = va;
     hipLaunchKernelGGL(lv_block_counts, dim3(nblk, C), dim3(256), 0, st, vals_out, target, P, nblk, hdr, bsum);
-    hipLaunchKernelGGL(lv_scan_blocks, dim3(1), dim3(64), 0, st, bsum, nblk, C, G, hdr);
+    hipLaunchKernelGGL(rs_scan, dim3(C), dim3(1024), 0, st, (unsigned*)bsum, nblk, (unsigned*)nullptr);
+    hipLaunchKernelGGL(lv_count_present, dim3(1), dim3(64), 0, st, C, G, hdr);
     hipLaunchKernelGGL(lv_final, dim3(nblk, C), dim3(256), 0, st, keys_out, vals_out, target, P, nblk, C, HW, G, bsum, hdr,
                        closs, dscores, gscale, gscale_dev);
     hipLaunchKernelGGL(lv_loss, dim3(1), dim3(64), 0, st, closs, G, C, hdr, loss_out);
