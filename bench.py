@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no HIP-graph replay)")
     ap.add_argument("--roofline-steps", type=int, default=2)
     ap.add_argument("--conv-tap-inner", type=int, default=None, help="override EESEG_OPT_CONV_TAP_INNER (0|1)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B switch: eeseg_set_option(KEY, VALUE) (include/eeseg.h EESEG_OPT_*); repeatable")
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
@@ -125,6 +127,10 @@ def main():
     from ee_semantic_segmentation_amd._lib import lib as _eelib
     if args.conv_tap_inner is not None:
         _eelib().eeseg_set_option(2, args.conv_tap_inner)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        if _eelib().eeseg_set_option(int(k), int(v)) != 0:
+            raise SystemExit(f"bad --opt {kv}")
     if args.conv_pipe is not None:
         _eelib().eeseg_set_option(1, args.conv_pipe)
     if args.ew_grid_cap is not None:

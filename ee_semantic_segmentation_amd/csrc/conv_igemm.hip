@@ -27,7 +27,8 @@ struct ConvP {
     uint32_t xbytes, wbytes;
     int vec_ok;   // 1: 16-byte row stores allowed (alignment / Cout multiple)
     int tap_inner;   // LINEAR kernels: K order (0 = taps outer / channels inner, 1 = taps inner)
-    int tile_begin, ksplit;   // 256x256 kernel: first tile of this launch, K ranges per tile
+    int tile_begin, ksplit;   // 256x256 kernel: first tile of this launch (MODE 0/1) or of the split tail (MODE 2), K ranges per tile
+    int n_split_blocks;       // MODE 2: leading blocks that work on K ranges of the tail tiles
     float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
 };
 
@@ -487,11 +488,16 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int unit = xcd_remap(blockIdx.x, gridDim.x);
-    const int nsplit = (MODE == 1) ? p.ksplit : 1;
-    const int tile_local = (MODE == 1) ? unit / nsplit : unit;
-    const int split = (MODE == 1) ? unit - tile_local * nsplit : 0;
-    const int tile = p.tile_begin + tile_local;
+    // MODE 2 (mixed launch): the first p.n_split_blocks blocks are K ranges of the tail tiles (they are dispatched
+    // first and finish early), the others are whole tiles 0 .. p.tile_begin-1 - one launch, no idle gap between the two
+    const int nsb = (MODE == 2) ? p.n_split_blocks : 0;
+    const bool split_blk = (MODE == 1) || (MODE == 2 && (int)blockIdx.x < nsb);
+    const int unit = split_blk ? (MODE == 2 ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x))
+                               : xcd_remap(blockIdx.x - nsb, gridDim.x - nsb);
+    const int nsplit = split_blk ? p.ksplit : 1;
+    const int tile_local = split_blk ? unit / nsplit : unit;
+    const int split = split_blk ? unit - tile_local * nsplit : 0;
+    const int tile = (split_blk || MODE == 0) ? p.tile_begin + tile_local : tile_local;
     const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
     const int m0 = mt * BIGT, n0 = nt * BIGT;
     const int wc = wave & 3, wp = wave >> 2;
@@ -550,8 +556,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         const unsigned tapmask = *sMask;
         const int kc_steps = p.Cin / 64;
         const int nk_all = __popc(tapmask) * kc_steps;
-        const int k_begin = (MODE == 1) ? (int)((long long)split * nk_all / nsplit) : 0;
-        const int k_end = (MODE == 1) ? (int)((long long)(split + 1) * nk_all / nsplit) : nk_all;
+        const int k_begin = split_blk ? (int)((long long)split * nk_all / nsplit) : 0;
+        const int k_end = split_blk ? (int)((long long)(split + 1) * nk_all / nsplit) : nk_all;
         const int nk = k_end - k_begin;
         __syncthreads();                   // sMask lies inside the epilogue staging area
 
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         BIG_BARRIER();
     }
 
-    if constexpr (MODE == 1) {             // partial sums of this K range, register layout: 1 KiB per wave store
+    if (split_blk) {                       // partial sums of this K range, register layout: 1 KiB per wave store
         if (p.stats && split == 0) {       // the fix-up kernel adds its 32-pixel slices into this tile's two stat rows
             const int which = tid >> 8, col = tid & 255;
             p.stats[((size_t)(2 * mt) * 2 + which) * p.Cout + n0 + col] = 0.f;
@@ -928,6 +934,7 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
 }
 
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
+int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
 
 // launch plan for the 256x256 kernel: full rounds of 256 tiles, then the remainder split along K
 int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long workspace_bytes) {
@@ -949,12 +956,18 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     }
     p.slabs = reinterpret_cast<float*>(workspace);
     p.ksplit = ksplit;
-    if (rounds > 0) {
-        p.tile_begin = 0;
-        hipLaunchKernelGGL(conv_big_kernel<0>, dim3(rounds * 256), dim3(512), 0, st, p);
-    }
     p.tile_begin = rounds * 256;
-    hipLaunchKernelGGL(conv_big_kernel<1>, dim3(rem * ksplit), dim3(512), 0, st, p);
+    p.n_split_blocks = rem * ksplit;
+    if (rounds > 0 && g_conv_big_merge)        // one launch: K-range blocks first, whole tiles behind them
+        hipLaunchKernelGGL(conv_big_kernel<2>, dim3(rem * ksplit + rounds * 256), dim3(512), 0, st, p);
+    else {
+        if (rounds > 0) {
+            ConvP q = p;
+            q.tile_begin = 0;
+            hipLaunchKernelGGL(conv_big_kernel<0>, dim3(rounds * 256), dim3(512), 0, st, q);
+        }
+        hipLaunchKernelGGL(conv_big_kernel<1>, dim3(rem * ksplit), dim3(512), 0, st, p);
+    }
     hipLaunchKernelGGL(conv_big_fixup_kernel, dim3(rem * 8), dim3(256), 0, st, p);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
@@ -1000,6 +1013,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_narrow_max = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_TAIL_MERGE && (value == 0 || value == 1)) {
+        g_conv_big_merge = value;
+        return EESEG_OK;
+    }
     if (key == EESEG_OPT_CE_SPAN && (value == 0 || value == 1)) {
         g_ce_span = value;
         return EESEG_OK;
@@ -1024,6 +1041,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_AUTO_NARROW: return g_conv_auto_narrow;
         case EESEG_OPT_CONV_TAIL_MIN: return g_conv_big_tail_min;
         case EESEG_OPT_CE_SPAN: return g_ce_span;
+        case EESEG_OPT_CONV_TAIL_MERGE: return g_conv_big_merge;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1073,7 +1091,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
-    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr;
+    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0;
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;

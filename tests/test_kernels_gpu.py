@@ -459,6 +459,7 @@ def test_bn_reduce_finalize_fused_equals_two_step():
     (3, 19, 23, 256, 512, 3, 1, 1, 1),        # two cout tiles, M not a multiple of 256 (+ dgrad)
     (1, 9, 9, 64, 256, 3, 1, 2, 2),           # fewer pixels than one tile
     (2, 31, 31, 256, 256, 3, 2, 1, 1),        # strided forward (smul = 2)
+    (2, 96, 96, 64, 1024, 1, 1, 0, 1),        # 288 tiles: one full round of 256 + a K-split tail in the SAME launch
 ])
 def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     """EESEG_OPT_CONV_PIPE=3 (256x256 tile, loads in flight across barriers) accumulates in the same K order
@@ -475,9 +476,10 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     res = None
     outs = {}
     try:
-        for name, pipe, tail in (("ref", 0, 224), ("big", 3, 0), ("split", 3, 224)):
+        for name, pipe, tail, merge in (("ref", 0, 224, 1), ("big", 3, 0, 1), ("split", 3, 224, 1), ("split2", 3, 224, 0)):
             lib().eeseg_set_option(1, pipe)
             lib().eeseg_set_option(5, tail)
+            lib().eeseg_set_option(7, merge)       # tail blocks in the main launch (default) or in their own
             y, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
             if res is None:
                 res = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
@@ -486,9 +488,13 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
             torch.cuda.synchronize()
             outs[name] = (y, K.reduce_partials(part), y2, dx)
     finally:
-        lib().eeseg_set_option(1, 0)
+        lib().eeseg_set_option(1, 3)
         lib().eeseg_set_option(5, 224)
+        lib().eeseg_set_option(7, 1)
     ref = outs["ref"]
+    for i in (0, 2, 3):                    # merged and separate tail launches do the same arithmetic
+        if outs["split"][i] is not None:
+            assert torch.equal(outs["split"][i], outs["split2"][i])
     assert torch.equal(ref[0], outs["big"][0])
     assert torch.equal(ref[2], outs["big"][2])
     close(outs["big"][1], ref[1], 1e-5, "BN partial sums")
