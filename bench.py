@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no HIP-graph replay)")
     ap.add_argument("--roofline-steps", type=int, default=2)
     ap.add_argument("--conv-tap-inner", type=int, default=None, help="override EESEG_OPT_CONV_TAP_INNER (0|1)")
+    ap.add_argument("--wgrad-big-grid", type=str, default=None, metavar="BLOCKS,ROUNDS",
+                    help="eeseg_set_wgrad_big_grid: concurrent blocks / max rounds of the 256x256 wgrad kernel")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch: eeseg_set_option(KEY, VALUE) (include/eeseg.h EESEG_OPT_*); repeatable")
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
@@ -127,6 +129,10 @@ def main():
     from ee_semantic_segmentation_amd._lib import lib as _eelib
     if args.conv_tap_inner is not None:
         _eelib().eeseg_set_option(2, args.conv_tap_inner)
+    if args.wgrad_big_grid:
+        b, r = [int(v) for v in args.wgrad_big_grid.split(",")]
+        if _eelib().eeseg_set_wgrad_big_grid(b, r) != 0:
+            raise SystemExit("bad --wgrad-big-grid")
     for kv in args.opt:
         k, v = kv.split("=")
         if _eelib().eeseg_set_option(int(k), int(v)) != 0:

@@ -534,10 +534,19 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p) {
 
 int g_wgrad_big = 1;                // eeseg_set_wgrad_big(0|1)
 int g_wgrad_big_min_ktiles = 20;
+int g_wgrad_big_blocks = 256;       // EESEG_OPT_WGRAD_BIG_BLOCKS: concurrent blocks the 256x256 wgrad kernel sizes its K split for
+int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this many rounds of them
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
 int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
 
 }  // namespace
+
+extern "C" int eeseg_set_wgrad_big_grid(int blocks, int rounds) {
+    EESEG_CHECK(blocks >= 16 && blocks <= 1024 && rounds >= 1 && rounds <= 64, EESEG_ERR_ARG, "set_wgrad_big_grid: out of range");
+    g_wgrad_big_blocks = blocks;
+    g_wgrad_big_rounds = rounds;
+    return EESEG_OK;
+}
 
 extern "C" int64_t eeseg_wgrad_workspace(void) {
     return 2048ll * 65536 * 4;           // tiles * splits <= 2048 slabs of 256 KiB
@@ -596,9 +605,10 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         const long long max_splits = (M + 8 * 64 - 1) / (8 * 64);          // at least 8 K tiles per block
         long long best = 1;
         double best_eff = 0.0;
-        for (long long sp = 1; sp <= max_splits && tiles * sp <= 2048; ++sp) {
+        const long long T = g_wgrad_big_blocks;                              // blocks that run at once (256 = whole chip)
+        for (long long sp = 1; sp <= max_splits && tiles * sp <= T * g_wgrad_big_rounds; ++sp) {
             const long long blocks = tiles * sp;
-            const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
+            const double eff = (double)blocks / (double)((blocks + T - 1) / T * T);
             if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
         }
         long long chunk = (M + best - 1) / best;

@@ -57,6 +57,10 @@ int eeseg_set_wgrad_target_blocks(int blocks);
  * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel); +4 = combine the K splits through
  * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics */
 int eeseg_set_wgrad_big(int on);
+/* K-split sizing of the 256x256 weight-gradient kernel: aim at `blocks` concurrent blocks (default 256 = one per CU) and
+ * at most `rounds` rounds of them (default 8).  Fewer blocks = fewer fp32 partial tiles to combine; use with the weight
+ * gradient on a side stream so that the other CUs are not idle. */
+int eeseg_set_wgrad_big_grid(int blocks, int rounds);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision

@@ -14,14 +14,15 @@ def short(n):
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"GPU busy per step: {tot / steps / 1e6:.2f} ms over {steps:g} steps, {sum(int(r['Calls']) for r in rows) / steps:.0f} launches/step\n", file=out)
 print("| kernel | calls/step | ms/step | % | avg us |\n|---|---:|---:|---:|---:|", file=out)
-# the 256x256 conv call = conv_big_kernel<0> (full rounds) [+ conv_big_kernel<1> (K-split tail) + conv_big_fixup_kernel]:
-# report the per-call aggregate as well (what bench.py's HIP events bracket); calls = launches of <0>
+# one 256x256 conv call = ONE conv_big_kernel<MODE> launch (<0> whole tiles only, <2> K-split tail blocks + whole tiles,
+# <1> K ranges only when there is no full round) [+ conv_big_fixup_kernel]: report the per-call aggregate as well (what
+# bench.py's HIP events bracket); calls = launches of conv_big_kernel<*>
 big = [r for r in rows if "conv_big" in r["Name"]]
 if big:
-    calls = sum(int(r["Calls"]) for r in big if "conv_big_kernel<0>" in r["Name"] or "conv_big_kernelILi0" in r["Name"])
+    calls = sum(int(r["Calls"]) for r in big if "conv_big_kernel" in r["Name"])
     tns = sum(float(r["TotalDurationNs"]) for r in big)
     if calls:
-        print(f"| conv_big_kernel<bf16,256x256> per CALL (sum of the {len(big)} kernels below / launches of <0>) | {calls / steps:.1f} | "
+        print(f"| conv_big_kernel<bf16,256x256> per CALL (sum of the {len(big)} kernels below / launches of conv_big_kernel<*>) | {calls / steps:.1f} | "
               f"{tns / steps / 1e6:.3f} | {100 * tns / tot:.1f} | {tns / calls / 1e3:.1f} |", file=out)
 for r in rows[:32]:
     print(f"| {short(r['Name'])} | {int(r['Calls']) / steps:.1f} | {float(r['TotalDurationNs']) / steps / 1e6:.3f} | "
