@@ -573,21 +573,38 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
             voffW[k] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * 2 + gchunk * 16) : EESEG_OOB;
             voffA[k] = EESEG_OOB; voffWl[k] = EESEG_OOB;
         }
-        // block-uniform iterator over the K tiles (taps outer, channels inner), starting at K tile k_begin
+        // block-uniform iterator over the K tiles, starting at K tile k_begin.  Two K orders (p.tap_inner):
+        //   0: taps outer, channel chunks inner - one gather-offset update per tap;
+        //   1: channel chunks outer, taps inner - all taps of one 128-byte channel slice back to back, so a 3x3 conv
+        //      re-reads that slice from L2 instead of streaming the whole input tensor once per tap from beyond L2.
+        const int nvis = __popc(tapmask);
+        const int rcpS = (65536 + p.S - 1) / p.S;           // tap / S for tap < 32 without a division
         unsigned rest = tapmask;
-        for (int i = k_begin / kc_steps; i > 0; --i) rest &= rest - 1;
-        int ci = k_begin % kc_steps - 1, cur_tap = 0, dtap = 0, soffA = 0, soffW = 0, remain = nk;
+        int ci, cur_tap = 0, dtap = 0, soffA = 0, soffW = 0, remain = nk;
         bool live = true, upd = true;
         auto pop_tap = [&]() {
             cur_tap = rest ? __ffs(rest) - 1 : 0;
             rest &= rest - 1;
-            const int r = cur_tap / p.S, s = cur_tap - r * p.S;
+            const int r = (cur_tap * rcpS) >> 16, s = cur_tap - r * p.S;
             dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * 2;
             upd = true;
         };
-        if (ci >= 0) pop_tap(); else ci = kc_steps - 1;      // mid-tap start: that tap is current; else the first call pops
+        if (p.tap_inner) {
+            ci = nvis ? k_begin / nvis : 0;
+            for (int i = nvis ? k_begin % nvis : 0; i > 0; --i) rest &= rest - 1;
+        } else {
+            for (int i = k_begin / kc_steps; i > 0; --i) rest &= rest - 1;
+            ci = k_begin % kc_steps - 1;
+            if (ci >= 0) pop_tap(); else ci = kc_steps - 1;  // mid-tap start: that tap is current; else the first call pops
+        }
         auto next_tile = [&]() {
-            if (++ci >= kc_steps) { ci = 0; pop_tap(); }
+            if (p.tap_inner) {
+                if (!rest) { rest = tapmask; ++ci; }
+                pop_tap();
+            } else if (++ci >= kc_steps) {
+                ci = 0;
+                pop_tap();
+            }
             if (remain-- == 0) { live = false; upd = true; }  // past the last tile: out-of-range (zero, no traffic) loads
             if (upd) {
                 upd = false;
