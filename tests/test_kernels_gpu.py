@@ -476,10 +476,12 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     res = None
     outs = {}
     try:
-        for name, pipe, tail, merge in (("ref", 0, 224, 1), ("big", 3, 0, 1), ("split", 3, 224, 1), ("split2", 3, 224, 0)):
+        for name, pipe, tail, merge, inner in (("ref", 0, 224, 1, 0), ("big", 3, 0, 1, 0), ("split", 3, 224, 1, 0),
+                                               ("split2", 3, 224, 0, 0), ("inner", 3, 224, 1, 1)):
             lib().eeseg_set_option(1, pipe)
             lib().eeseg_set_option(5, tail)
             lib().eeseg_set_option(7, merge)       # tail blocks in the main launch (default) or in their own
+            lib().eeseg_set_option(2, inner)       # K order: taps outer (default) / taps inner
             y, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
             if res is None:
                 res = torch.randn(y.shape, generator=g).to(DEV).bfloat16()
@@ -491,7 +493,11 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
         lib().eeseg_set_option(1, 3)
         lib().eeseg_set_option(5, 224)
         lib().eeseg_set_option(7, 1)
+        lib().eeseg_set_option(2, 0)
     ref = outs["ref"]
+    for i, what in ((0, "y"), (2, "fused epilogue"), (3, "dgrad")):      # taps-inner K order: another summation order
+        if ref[i] is not None:
+            close(outs["inner"][i], ref[i], 8e-3, f"taps-inner {what}")
     for i in (0, 2, 3):                    # merged and separate tail launches do the same arithmetic
         if outs["split"][i] is not None:
             assert torch.equal(outs["split"][i], outs["split2"][i])
