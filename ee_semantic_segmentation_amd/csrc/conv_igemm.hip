@@ -1,4 +1,8 @@
-// Implicit-GEMM convolution for gfx950 (forward and data-gradient).
+// Implicit-GEMM convolution for gfx950 (forward and data-gradient).  Two kernels:
+//   conv_big_kernel  (further down): 256 px x 256 cout tile, 8 waves, one block per CU, LDS-DMA loads in flight across
+//                    raw barriers - bf16 layers with Cout % 256 == 0 and a stride-1 gather (the default for them);
+//   conv_igemm_kernel (below): 128 px x 128/64 cout tile, 4 waves, 2-3 blocks per CU - everything else (fp32 parity
+//                    mode, narrow layers, strided data-gradient).
 //
 // GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (tap, cin).
 //   A operand = weight tile (rows = cout), B operand = gathered pixel tile, so the
