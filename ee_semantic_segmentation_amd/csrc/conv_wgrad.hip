@@ -258,6 +258,8 @@ constexpr int WB_LDS = 8 * WHT;
 #define WB_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WB_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// FAST: 64 consecutive pixels span at most two image rows (Wout > 64): the in-loop iterator is straight-line code.
+template <bool FAST>
 __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef __attribute__((address_space(3))) s16x4* lds_tr;
@@ -286,66 +288,165 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         coW[i] = (co0 + i * 128 + lc) * 2;        // a half tile = 128 CONTIGUOUS channels: whole 128-byte lines per DMA row
         ciX[i] = (ci0 + i * 128 + lc) * 2;
     }
-    int pm[2], pn[2], ph[2], pw[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        pm[q] = ps + q * 32 + drow;
-        pn[q] = pm[q] / p.HWout;
-        const int rem = pm[q] - pn[q] * p.HWout;
-        ph[q] = rem / p.Wout;
-        pw[q] = rem - ph[q] * p.Wout;
-    }
     const __amdgpu_buffer_rsrc_t rdy = make_rsrc(p.dy, p.dybytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
 
-    // K-tile iterator.  Everything advances by additions only (64 pixels = q64 rows + r64 columns, host-computed;
-    // the host guarantees q64 + 1 <= Hout so one conditional subtraction wraps a row/image counter): the iterator
-    // runs in the LDS-read slot of a phase and must stay far below the 256 MFMA cycles of the other wave group.
-    int t_h, t_w;                              // block-uniform: image row / column of the first pixel of K tile kt
+    // K-tile iterator.  It runs once per K tile inside an LDS-read slot, opposite the other wave group's 8 MFMAs
+    // (256 cycles): measured with in-kernel cycle stamps, the first version (index -> offset multiplies, nested
+    // wrap loops) made that slot 1280 cycles long and the whole K tile 4000 instead of ~2600.  So: every quantity
+    // advances by ADDITIONS of block constants (64 pixels = q64 rows + r64 columns; the host guarantees
+    // q64 + 1 <= Hout so one conditional correction wraps a counter), no multiplies, no data-dependent loops
+    // except the rare skip of all-padding tiles.
+    const int st = p.stride;
+    const int c_dy = 64 * p.lddy * 2;                                        // dY bytes per K tile
+    const int c_x = (p.q64 * st * p.Win + p.r64 * st) * p.Cin * 2;           // X bytes per K tile, no wrap
+    const int c_xw = (st * p.Win - p.Wout * st) * p.Cin * 2;                 // correction when the column wraps
+    const int c_xh = (p.Hin * p.Win - p.Hout * st * p.Win) * p.Cin * 2;      // correction when the row wraps (next image)
+    const int tapc = (dh * p.Win + dwv) * p.Cin * 2;                         // this block's tap shift
+    int pm[2], phs[2], pws[2], xoff[2], dyoff[2];   // pixel index, row*stride, column*stride, byte offsets (tap 0,0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pm[q] = ps + q * 32 + drow;
+        const int n = pm[q] / p.HWout;
+        const int rem = pm[q] - n * p.HWout;
+        const int h = rem / p.Wout, w = rem - h * p.Wout;
+        phs[q] = h * st; pws[q] = w * st;
+        xoff[q] = (((n * p.Hin + phs[q]) * p.Win + pws[q]) * p.Cin) * 2;
+        dyoff[q] = pm[q] * p.lddy * 2;
+    }
+    int t_hs, t_w;                             // block-uniform: row*stride / column of the first pixel of K tile kt
     {
         const int rem0 = ps % p.HWout;
-        t_h = rem0 / p.Wout;
-        t_w = rem0 - t_h * p.Wout;
+        const int h0 = rem0 / p.Wout;
+        t_hs = h0 * st;
+        t_w = rem0 - h0 * p.Wout;
     }
+    const int Hs = p.Hout * st, Ws = p.Wout * st, qs = p.q64 * st, rs = p.r64 * st;
     auto tile_valid = [&]() {                  // any tap-shifted source row of the 64 pixels inside the image?
-        int r = t_h, rem = t_w + 63;
+        if (dh == 0) return true;
+        int r = t_hs, rem = t_w + 63;
         bool ok = false;
         for (;;) {
-            ok = ok || ((unsigned)(r * p.stride + dh) < (unsigned)p.Hin);
+            ok = ok || ((unsigned)(r + dh) < (unsigned)p.Hin);
             if (rem < p.Wout) break;
             rem -= p.Wout;
-            r = (r + 1 == p.Hout) ? 0 : r + 1;
+            r = (r + st == Hs) ? 0 : r + st;
         }
         return ok;
     };
+    auto step_rows = [&]() {                   // everything advances by one K tile: additions and selects only
+        t_w += p.r64; t_hs += qs;
+        const bool tw = t_w >= p.Wout;
+        t_w -= tw ? p.Wout : 0; t_hs += tw ? st : 0;
+        t_hs -= (t_hs >= Hs) ? Hs : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            pm[q] += 64; dyoff[q] += c_dy;
+            pws[q] += rs; phs[q] += qs; xoff[q] += c_x;
+            const bool ww = pws[q] >= Ws;
+            pws[q] -= ww ? Ws : 0; phs[q] += ww ? st : 0; xoff[q] += ww ? c_xw : 0;
+            const bool hw = phs[q] >= Hs;
+            phs[q] -= hw ? Hs : 0; xoff[q] += hw ? c_xh : 0;
+        }
+    };
     int kt = -1;
     uint32_t voffDY[2] = {EESEG_OOB, EESEG_OOB}, voffX[2] = {EESEG_OOB, EESEG_OOB};
-    auto next_tile = [&]() -> bool {           // advance to the next K tile that is not all padding
+    auto set_offsets = [&](bool live) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool in = live && pm[q] < pe;
+            voffDY[q] = in ? (uint32_t)dyoff[q] : EESEG_OOB;
+            const bool ok = in && (unsigned)(phs[q] + dh) < (unsigned)p.Hin && (unsigned)(pws[q] + dwv) < (unsigned)p.Win;
+            voffX[q] = ok ? (uint32_t)(xoff[q] + tapc) : EESEG_OOB;
+        }
+    };
+    auto next_tile = [&]() -> bool {           // general form (prologue): advance to the next K tile that is not all padding
         bool live;
         for (;;) {
-            if (kt >= 0) {                     // (kt == -1: the rows already sit on K tile 0)
-                t_w += p.r64; t_h += p.q64;
-                if (t_w >= p.Wout) { t_w -= p.Wout; ++t_h; }
-                if (t_h >= p.Hout) t_h -= p.Hout;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    pm[q] += 64; pw[q] += p.r64; ph[q] += p.q64;
-                    if (pw[q] >= p.Wout) { pw[q] -= p.Wout; ++ph[q]; }
-                    if (ph[q] >= p.Hout) { ph[q] -= p.Hout; ++pn[q]; }
-                }
-            }
+            if (kt >= 0) step_rows();          // (kt == -1: the rows already sit on K tile 0)
             ++kt;
             live = kt < nk_all;
             if (!live || tile_valid()) break;
         }
+        set_offsets(live);
+        return live;
+    };
+    // FAST form (Wout > 64: a K tile of 64 consecutive pixels crosses at most one row boundary).  The whole position
+    // state is block-uniform (scalar registers): pixel index, image row/column, dY and X byte offsets of the tile's
+    // first pixel, all advanced by additions.  A thread derives its two rows from it with a handful of selects
+    // (row j = q*32 + drow sits before or after the row boundary) - no per-thread running state, no multiplies.
+    int um = ps, uA = 0, uDY = 0;              // first pixel of K tile kt: index, X offset (tap 0,0), dY offset
+    int jx[2], jd[2];
+    if constexpr (FAST) {
+        const int n0 = ps / p.HWout;
+        uA = (((n0 * p.Hin + t_hs) * p.Win + t_w * st) * p.Cin) * 2;
+        uDY = ps * p.lddy * 2;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool in = live && pm[q] < pe;
-            voffDY[q] = in ? (uint32_t)(pm[q] * p.lddy * 2) : EESEG_OOB;
-            const int hi = ph[q] * p.stride + dh, wi = pw[q] * p.stride + dwv;
-            const bool ok = in && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win;
-            voffX[q] = ok ? (uint32_t)((((pn[q] * p.Hin + hi) * p.Win + wi) * p.Cin) * 2) : EESEG_OOB;
+            jx[q] = (q * 32 + drow) * st * p.Cin * 2;
+            jd[q] = (q * 32 + drow) * p.lddy * 2;
         }
+    }
+    bool need_skip = false;
+    // (written with selects and non-short-circuit & | only: no branch, so that the in-loop call stays in the basic
+    // block of the MFMAs it is scheduled between)
+    auto u_step = [&]() {                      // scalar: one K tile forward
+        um += 64; uDY += c_dy; uA += 64 * st * p.Cin * 2;
+        t_w += 64;
+        const int cw = (t_w >= p.Wout) ? 1 : 0;                 // column wrap
+        t_w -= cw ? p.Wout : 0; t_hs += cw ? st : 0; uA += cw ? c_xw : 0;
+        const int ch = (t_hs >= Hs) ? 1 : 0;                    // row wrap: next image
+        t_hs -= ch ? Hs : 0; uA += ch ? c_xh : 0;
+    };
+    auto u_valid = [&]() -> int {              // scalar: does the tile touch a source row inside the image?
+        const int r2 = (t_hs + st == Hs) ? 0 : t_hs + st;
+        const int v1 = ((unsigned)(t_hs + dh) < (unsigned)p.Hin) ? 1 : 0;
+        const int v2 = (((p.Wout - t_w) <= 63) ? 1 : 0) & (((unsigned)(r2 + dh) < (unsigned)p.Hin) ? 1 : 0);
+        return ((dh == 0) ? 1 : 0) | v1 | v2;
+    };
+    auto u_offsets = [&](int live) {
+        const int wrap_pos = p.Wout - t_w;     // rows j >= wrap_pos belong to the next image row
+        const int last_row = (t_hs + st == Hs) ? 1 : 0;
+        const int r2 = last_row ? 0 : t_hs + st;
+        const int wrapc = c_xw + (last_row ? c_xh : 0);
+        const int ok1 = ((unsigned)(t_hs + dh) < (unsigned)p.Hin) ? 1 : 0, ok2 = ((unsigned)(r2 + dh) < (unsigned)p.Hin) ? 1 : 0;
+        const int nvalid = live ? pe - um : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = q * 32 + drow;
+            const int seg = (j >= wrap_pos) ? 1 : 0;
+            const int w = seg ? j - wrap_pos : t_w + j;
+            const int in = (j < nvalid) ? 1 : 0;
+            const int ok = in & (seg ? ok2 : ok1) & (((unsigned)(w * st + dwv) < (unsigned)p.Win) ? 1 : 0);
+            voffDY[q] = in ? (uint32_t)(uDY + jd[q]) : EESEG_OOB;
+            voffX[q] = ok ? (uint32_t)(uA + jx[q] + (seg ? wrapc : 0) + tapc) : EESEG_OOB;
+        }
+    };
+    auto u_first = [&]() -> bool {             // prologue, K tile 0 (or the first one that is not all padding)
+        kt = 0;
+        while (kt < nk_all && !u_valid()) { u_step(); ++kt; }
+        const bool live = kt < nk_all;
+        u_offsets(live ? 1 : 0);
+        return live;
+    };
+    auto advance_fast = [&]() -> bool {        // straight-line: schedulable between the MFMAs of the phase it rides in
+        u_step();
+        ++kt;
+        const int live = (kt < nk_all) ? 1 : 0;
+        need_skip = (live & (u_valid() ^ 1)) != 0;
+        u_offsets(live);
+        return live != 0;
+    };
+    auto advance_skip = [&]() -> bool {        // rare: the next K tile lies entirely in the padding
+        while (kt < nk_all && !u_valid()) { u_step(); ++kt; }
+        const bool live = kt < nk_all;
+        u_offsets(live ? 1 : 0);
+        need_skip = false;
+        return live;
+    };
+    auto adv = [&]() -> bool {                 // prologue form of the in-loop advance (skip handled at once)
+        bool live = advance_fast();
+        if (need_skip) live = advance_skip();
         return live;
     };
     const int w4 = __builtin_amdgcn_readfirstlane(wave) * 4;
@@ -355,11 +456,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(smem + (s * 4 + 2 + i) * WHT + (q * 32 + w4) * 256), 16,
                                                      (int)(voffDY[q] + coW[i]), 0, 0, 0);
     };
+    uint32_t xbsave[2] = {EESEG_OOB, EESEG_OOB};     // X offsets of the K tile whose XB half is issued one phase later
     auto dmaX = [&](int s, int h) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (s * 4 + h) * WHT + (q * 32 + w4) * 256), 16,
                                                      (int)(voffX[q] + ciX[h]), 0, 0, 0);
+    };
+    auto dmaXB_saved = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (s * 4 + 1) * WHT + (q * 32 + w4) * 256), 16,
+                                                     (int)(xbsave[q] + ciX[1]), 0, 0, 0);
     };
 
     const int wc = wave & 3, wp = wave >> 2;
@@ -421,11 +529,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // schedule and wait counts: see conv_big_kernel (phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2))
-    bool l0 = next_tile();
+    // the iterator sits in the light phase-4 slot (one DMA pair), one K tile ahead of the XB issue of phase 1, which
+    // therefore uses the X offsets saved before the advance
+    bool l0 = FAST ? u_first() : next_tile();
     const bool any = l0;
     dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);
-    bool l1 = next_tile();
+    bool l1 = FAST ? adv() : next_tile();
     dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);
+    xbsave[0] = voffX[0]; xbsave[1] = voffX[1];
+    bool l2 = FAST ? adv() : next_tile();      // state = K tile 2
     WB_WAIT(6);
     WB_BARRIER();
     const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
@@ -434,7 +546,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     while (l0) {
         const char* sb = smem + s * 4 * WHT;
         bf16x8 w0[4], w1[4], xa0[4], xa1[4], xb0[4], xb1[4];
-        dmaX(s ^ 1, 1);
+        dmaXB_saved(s ^ 1);
         rd(sb + 2 * WHT, wc * 32 + chl, w0); rd(sb, wp * 64 + chl, xa0); rd(sb, wp * 64 + 32 + chl, xa1);
         WB_WAIT(10);
         WB_BARRIER();
@@ -447,7 +559,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         lgk_wait4(w1);
         mma4(w1, xa0, xa1, acc[1][0], acc[1][1]);
         WB_BARRIER();
-        const bool l2 = next_tile();
         dmaX(s, 0); dmaW(s, 0);
         rd(sb + WHT, wp * 64 + chl, xb0); rd(sb + WHT, wp * 64 + 32 + chl, xb1);
         WB_BARRIER();
@@ -457,9 +568,28 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         dmaW(s, 1);
         WB_WAIT(10);
         WB_BARRIER();
-        mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+        // the iterator (pure register arithmetic, ~100 instructions) rides in the shadow of this phase's MFMAs: in a
+        // read slot it would add its full issue time to the K tile (2 x sum of the slot times is what one K tile costs)
+        xbsave[0] = voffX[0]; xbsave[1] = voffX[1];
+        bool l3;
+        if constexpr (FAST) {
+            l3 = advance_fast();
+            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+            // one MFMA, then a dozen of the iterator's VALU/SALU instructions, eight times: they issue while the matrix
+            // pipe works (the iterator and the MFMAs are independent and in one basic block)
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // VALU
+                __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);      // SALU
+            }
+            if (need_skip) l3 = advance_skip();
+        } else {
+            l3 = next_tile();
+            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+        }
         WB_BARRIER();
-        l0 = l1; l1 = l2; s ^= 1;
+        l0 = l1; l1 = l2; l2 = l3; s ^= 1;
     }
     if (!lagging) WB_BARRIER();
     WB_WAIT(0);
@@ -621,7 +751,10 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             const long long need = tiles * splits * 65536ll * 4;
             p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
                           ? reinterpret_cast<float*>(a->workspace) : nullptr;
-            hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
+            if (p.q64 == 0)
+                hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
+            else
+                hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
             if (p.slabs) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8)), dim3(256), 0, st, p);
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;

@@ -519,6 +519,9 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     (3, 19, 23, 256, 512, 3, 1, 1, 1),        # two cout tiles, ragged pixel count
     (1, 12, 12, 256, 256, 3, 1, 2, 2),        # few K tiles per block, 5 image rows per K tile
     (2, 31, 31, 256, 256, 3, 2, 1, 1),        # strided
+    (2, 20, 70, 256, 256, 3, 1, 6, 6),        # Wout > 64: the straight-line in-loop iterator (FAST form), atrous skips
+    (1, 30, 131, 256, 512, 1, 1, 0, 1),       # FAST form, 1x1, ragged
+    (2, 37, 141, 256, 256, 3, 2, 1, 1),       # FAST form, strided (Wout = 71)
 ])
 def test_wgrad_256_tile_kernel_matches_the_128_tile_kernel(shape):
     from ee_semantic_segmentation_amd._lib import lib
