@@ -662,43 +662,70 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         //     group has consumed its reads);
         //   * the wait that retires the loads of phase Q sits in phase Q-1 after the reads, before the barrier.
         // Issue order per iteration: phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2).
+        // The read slots hold nothing but LDS reads and the counted wait: every DMA issue and the K iterator sit INSIDE the
+        // MFMA blocks, pinned between the MFMAs (the wave has issue slack there; one K tile costs 2 x the sum of the four
+        // slot times).  A half tile last read in slot P is refilled in MFMA block P+1: by then the lagging
+        // group, half a phase behind, has consumed its slot-P reads too.  Issue order per iteration t (all for K tile t+2,
+        // stage s):  MFMA block 2: XA, W0 | block 3: W1 | block 4: XB;  waits (in slot P-1 for the reads of slot P) as before.
         next_tile(); dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);      // K tile 0
-        next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);                  // K tile 1 without XB
-        BIG_WAIT(6);
+        next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1); dmaX(1, 1);      // K tile 1
+        BIG_WAIT(8);
         BIG_BARRIER();
         const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
         if (lagging) BIG_BARRIER();
+        auto dma1 = [&](const __amdgpu_buffer_rsrc_t& rs, int half, int q, uint32_t voff, int soff, int s) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (s * 4 + half) * HT + (q * 64 + w8) * ROWB), 16,
+                                                     (int)voff, soff, 0, 0);
+        };
+#define EESEG_MM(a_, b_, c_) { Mma<T>::run(a_, b_, c_); __builtin_amdgcn_sched_barrier(0); }
         for (int t = 0; t < nk; ++t) {
             const int s = t & 1;
             const char* sb = smem + s * 4 * HT;
             Frag w0[4], w1[4], xa0[4], xa1[4], xb0[4], xb1[4];
-            // phase 1: quadrant (W0, XA); refill XB of the other stage (last read in phase 3 of the previous tile)
-            dmaX(s ^ 1, 1);
+            // phase 1: quadrant (W0, XA)
             rdW(sb, 0, w0); rdX(sb, 0, 0, xa0); rdX(sb, 0, 1, xa1);
             BIG_WAIT(10);                  // W1(t) landed
             BIG_BARRIER();
             mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+            next_tile();                   // -> K tile t+2 (in the shadow of the MFMAs just issued)
             BIG_BARRIER();
-            // phase 2: quadrant (W1, XA)
+            // phase 2: quadrant (W1, XA); XA(s), W0(s) were last read in slot 1: refill them between these MFMAs
             rdW(sb, 1, w1);
             BIG_WAIT(8);                   // XB(t) landed
             BIG_BARRIER();
-            mma4(w1, xa0, xa1, acc[1][0], acc[1][1]);
+            __builtin_amdgcn_s_setprio(1);
+            EESEG_MM(w1[0], xa0[0], acc[1][0]) dma1(rx, 0, 0, voffA[0], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[0], xa1[0], acc[1][1]) dma1(rx, 0, 1, voffA[1], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[1], xa0[1], acc[1][0]) dma1(rw, 2, 0, voffWl[0], soffW, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[1], xa1[1], acc[1][1]) dma1(rw, 2, 1, voffWl[1], soffW, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[2], xa0[2], acc[1][0]) EESEG_MM(w1[2], xa1[2], acc[1][1])
+            EESEG_MM(w1[3], xa0[3], acc[1][0]) EESEG_MM(w1[3], xa1[3], acc[1][1])
+            __builtin_amdgcn_s_setprio(0);
             BIG_BARRIER();
-            // phase 3: quadrant (W1, XB); refill XA, W0 (last read in phase 1) with K tile t+2
-            next_tile();
-            dmaX(s, 0); dmaW(s, 0);
+            // phase 3: quadrant (W1, XB); W1(s) was last read in slot 2
             rdX(sb, 1, 0, xb0); rdX(sb, 1, 1, xb1);
             BIG_BARRIER();
-            mma4(w1, xb0, xb1, acc[1][2], acc[1][3]);
+            __builtin_amdgcn_s_setprio(1);
+            EESEG_MM(w1[0], xb0[0], acc[1][2]) dma1(rw, 3, 0, voffWl[2], soffW, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[0], xb1[0], acc[1][3]) dma1(rw, 3, 1, voffWl[3], soffW, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w1[1], xb0[1], acc[1][2]) EESEG_MM(w1[1], xb1[1], acc[1][3])
+            EESEG_MM(w1[2], xb0[2], acc[1][2]) EESEG_MM(w1[2], xb1[2], acc[1][3])
+            EESEG_MM(w1[3], xb0[3], acc[1][2]) EESEG_MM(w1[3], xb1[3], acc[1][3])
+            __builtin_amdgcn_s_setprio(0);
             BIG_BARRIER();
-            // phase 4: quadrant (W0, XB) from registers; refill W1 (last read in phase 2)
-            dmaW(s, 1);
+            // phase 4: quadrant (W0, XB) from registers; XB(s) was last read in slot 3
             BIG_WAIT(10);                  // XA(t+1), W0(t+1) landed
             BIG_BARRIER();
-            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
+            __builtin_amdgcn_s_setprio(1);
+            EESEG_MM(w0[0], xb0[0], acc[0][2]) dma1(rx, 1, 0, voffA[2], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w0[0], xb1[0], acc[0][3]) dma1(rx, 1, 1, voffA[3], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_MM(w0[1], xb0[1], acc[0][2]) EESEG_MM(w0[1], xb1[1], acc[0][3])
+            EESEG_MM(w0[2], xb0[2], acc[0][2]) EESEG_MM(w0[2], xb1[2], acc[0][3])
+            EESEG_MM(w0[3], xb0[3], acc[0][2]) EESEG_MM(w0[3], xb1[3], acc[0][3])
+            __builtin_amdgcn_s_setprio(0);
             BIG_BARRIER();
         }
+#undef EESEG_MM
         if (!lagging) BIG_BARRIER();
         BIG_WAIT(0);                       // trailing out-of-range DMAs still write (zeros) into LDS
         BIG_BARRIER();
