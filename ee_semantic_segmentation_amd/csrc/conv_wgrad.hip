@@ -529,68 +529,89 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // schedule and wait counts: see conv_big_kernel (phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2))
-    // the iterator sits in the light phase-4 slot (one DMA pair), one K tile ahead of the XB issue of phase 1, which
-    // therefore uses the X offsets saved before the advance
+    // The read slots hold only the transposing LDS reads and the counted wait; DMA issues are pinned between the MFMAs
+    // (a half tile last read in slot P is refilled in MFMA block P+1: the lagging group has consumed its slot-P reads by
+    // then), the K iterator rides in MFMA block 1.  Issue order per iteration t, all for K tile t+2 (stage s):
+    //   MFMA block 2: XA, W0 | block 3: W1 | block 4: XB;  waits as in conv_big_kernel.
     bool l0 = FAST ? u_first() : next_tile();
     const bool any = l0;
     dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);
     bool l1 = FAST ? adv() : next_tile();
-    dmaX(1, 0); dmaW(1, 0); dmaW(1, 1);
-    xbsave[0] = voffX[0]; xbsave[1] = voffX[1];
-    bool l2 = FAST ? adv() : next_tile();      // state = K tile 2
-    WB_WAIT(6);
+    dmaX(1, 0); dmaW(1, 0); dmaW(1, 1); dmaX(1, 1);
+    WB_WAIT(8);
     WB_BARRIER();
     const bool lagging = __builtin_amdgcn_readfirstlane(wave) >= 4;
     if (lagging) WB_BARRIER();
+    auto dmaW1 = [&](int s, int i, int q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(smem + (s * 4 + 2 + i) * WHT + (q * 32 + w4) * 256), 16,
+                                                 (int)(voffDY[q] + coW[i]), 0, 0, 0);
+    };
+    auto dmaX1 = [&](int s, int h, int q) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + (s * 4 + h) * WHT + (q * 32 + w4) * 256), 16,
+                                                 (int)(voffX[q] + ciX[h]), 0, 0, 0);
+    };
+#define EESEG_WM(a_, b_, c_) { c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
     int s = 0;
     while (l0) {
         const char* sb = smem + s * 4 * WHT;
         bf16x8 w0[4], w1[4], xa0[4], xa1[4], xb0[4], xb1[4];
-        dmaXB_saved(s ^ 1);
         rd(sb + 2 * WHT, wc * 32 + chl, w0); rd(sb, wp * 64 + chl, xa0); rd(sb, wp * 64 + 32 + chl, xa1);
         WB_WAIT(10);
         WB_BARRIER();
         lgk_wait12(w0, xa0, xa1);
-        mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+        bool l2;
+        if constexpr (FAST) {
+            l2 = advance_fast();               // -> K tile t+2, straight-line code between the MFMAs
+            mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);
+            }
+            if (need_skip) l2 = advance_skip();
+        } else {
+            mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+            l2 = next_tile();
+        }
         WB_BARRIER();
         rd(sb + 3 * WHT, wc * 32 + chl, w1);
         WB_WAIT(8);
         WB_BARRIER();
         lgk_wait4(w1);
-        mma4(w1, xa0, xa1, acc[1][0], acc[1][1]);
+        __builtin_amdgcn_s_setprio(1);
+        EESEG_WM(w1[0], xa0[0], acc[1][0]) dmaX1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[0], xa1[0], acc[1][1]) dmaX1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[1], xa0[1], acc[1][0]) dmaW1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[1], xa1[1], acc[1][1]) dmaW1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[2], xa0[2], acc[1][0]) EESEG_WM(w1[2], xa1[2], acc[1][1])
+        EESEG_WM(w1[3], xa0[3], acc[1][0]) EESEG_WM(w1[3], xa1[3], acc[1][1])
+        __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
-        dmaX(s, 0); dmaW(s, 0);
         rd(sb + WHT, wp * 64 + chl, xb0); rd(sb + WHT, wp * 64 + 32 + chl, xb1);
         WB_BARRIER();
         lgk_wait8(xb0, xb1);
-        mma4(w1, xb0, xb1, acc[1][2], acc[1][3]);
+        __builtin_amdgcn_s_setprio(1);
+        EESEG_WM(w1[0], xb0[0], acc[1][2]) dmaW1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[0], xb1[0], acc[1][3]) dmaW1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w1[1], xb0[1], acc[1][2]) EESEG_WM(w1[1], xb1[1], acc[1][3])
+        EESEG_WM(w1[2], xb0[2], acc[1][2]) EESEG_WM(w1[2], xb1[2], acc[1][3])
+        EESEG_WM(w1[3], xb0[3], acc[1][2]) EESEG_WM(w1[3], xb1[3], acc[1][3])
+        __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
-        dmaW(s, 1);
         WB_WAIT(10);
         WB_BARRIER();
-        // the iterator (pure register arithmetic, ~100 instructions) rides in the shadow of this phase's MFMAs: in a
-        // read slot it would add its full issue time to the K tile (2 x sum of the slot times is what one K tile costs)
-        xbsave[0] = voffX[0]; xbsave[1] = voffX[1];
-        bool l3;
-        if constexpr (FAST) {
-            l3 = advance_fast();
-            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
-            // one MFMA, then a dozen of the iterator's VALU/SALU instructions, eight times: they issue while the matrix
-            // pipe works (the iterator and the MFMAs are independent and in one basic block)
-#pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // VALU
-                __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);      // SALU
-            }
-            if (need_skip) l3 = advance_skip();
-        } else {
-            l3 = next_tile();
-            mma4(w0, xb0, xb1, acc[0][2], acc[0][3]);
-        }
+        __builtin_amdgcn_s_setprio(1);
+        EESEG_WM(w0[0], xb0[0], acc[0][2]) dmaX1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w0[0], xb1[0], acc[0][3]) dmaX1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+        EESEG_WM(w0[1], xb0[1], acc[0][2]) EESEG_WM(w0[1], xb1[1], acc[0][3])
+        EESEG_WM(w0[2], xb0[2], acc[0][2]) EESEG_WM(w0[2], xb1[2], acc[0][3])
+        EESEG_WM(w0[3], xb0[3], acc[0][2]) EESEG_WM(w0[3], xb1[3], acc[0][3])
+        __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
-        l0 = l1; l1 = l2; l2 = l3; s ^= 1;
+        l0 = l1; l1 = l2; s ^= 1;
     }
+#undef EESEG_WM
     if (!lagging) WB_BARRIER();
     WB_WAIT(0);
     if (p.slabs) {
