@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--conv-tap-inner", type=int, default=None, help="override EESEG_OPT_CONV_TAP_INNER (0|1)")
     ap.add_argument("--wgrad-big-grid", type=str, default=None, metavar="BLOCKS,ROUNDS",
                     help="eeseg_set_wgrad_big_grid: concurrent blocks / max rounds of the 256x256 wgrad kernel")
+    ap.add_argument("--wgrad-big-min-ktiles", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch: eeseg_set_option(KEY, VALUE) (include/eeseg.h EESEG_OPT_*); repeatable")
     ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
@@ -129,6 +130,8 @@ def main():
     from ee_semantic_segmentation_amd._lib import lib as _eelib
     if args.conv_tap_inner is not None:
         _eelib().eeseg_set_option(2, args.conv_tap_inner)
+    if args.wgrad_big_min_ktiles is not None:
+        _eelib().eeseg_set_wgrad_big_min_ktiles(args.wgrad_big_min_ktiles)
     if args.wgrad_big_grid:
         b, r = [int(v) for v in args.wgrad_big_grid.split(",")]
         if _eelib().eeseg_set_wgrad_big_grid(b, r) != 0:

@@ -47,6 +47,7 @@ SIGNATURES = {
     "eeseg_set_wgrad_target_blocks": (_i, [_i]),
     "eeseg_set_wgrad_big": (_i, [_i]),
     "eeseg_set_wgrad_big_grid": (_i, [_i, _i]),
+    "eeseg_set_wgrad_big_min_ktiles": (_i, [_i]),
     "eeseg_conv_stats_tiles": (_i, [_i, _i, _i]),
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_workspace": (_i64, []),

@@ -692,6 +692,12 @@ int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_
 
 }  // namespace
 
+extern "C" int eeseg_set_wgrad_big_min_ktiles(int n) {
+    EESEG_CHECK(n >= 1 && n <= 4096, EESEG_ERR_ARG, "set_wgrad_big_min_ktiles: out of range");
+    g_wgrad_big_min_ktiles = n;
+    return EESEG_OK;
+}
+
 extern "C" int eeseg_set_wgrad_big_grid(int blocks, int rounds) {
     EESEG_CHECK(blocks >= 16 && blocks <= 1024 && rounds >= 1 && rounds <= 64, EESEG_ERR_ARG, "set_wgrad_big_grid: out of range");
     g_wgrad_big_blocks = blocks;

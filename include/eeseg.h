@@ -61,6 +61,8 @@ int eeseg_set_wgrad_big(int on);
  * at most `rounds` rounds of them (default 8).  Fewer blocks = fewer fp32 partial tiles to combine; use with the weight
  * gradient on a side stream so that the other CUs are not idle. */
 int eeseg_set_wgrad_big_grid(int blocks, int rounds);
+/* the 256x256 weight-gradient kernel is used when every block gets at least this many K tiles (default 20) */
+int eeseg_set_wgrad_big_min_ktiles(int n);
 
 /* ---------------------------------------------------------------- conv ----
  * Implicit-GEMM convolution.  Replaces F.conv2d reached via torchvision
