@@ -34,6 +34,8 @@ struct ConvP {
     int tile_begin, ksplit;   // 256x256 kernel: first tile of this launch (MODE 0/1) or of the split tail (MODE 2), K ranges per tile
     int n_split_blocks;       // MODE 2: leading blocks that work on K ranges of the tail tiles
     float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
+    int pointwise;            // 256x256 kernel: 1x1, stride 1, no padding (source pixel = output pixel)
+    int skew;                 // 256x256 kernel: start delay (10-ns ticks) of every other group of 8 first-round blocks
 };
 
 template <typename T> struct Mma;
@@ -492,6 +494,12 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // short-K layers run load / MFMA / store phases in lock step on all CUs and each phase then queues on HBM: delaying
+    // half of the first-round blocks (one group of 8 = one block per XCD in two) puts the two halves in opposite phases
+    if (p.skew > 0 && (int)blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)p.skew) __builtin_amdgcn_s_sleep(32);
+    }
     // MODE 2 (mixed launch): the first p.n_split_blocks blocks are K ranges of the tail tiles (they are dispatched
     // first and finish early), the others are whole tiles 0 .. p.tile_begin-1 - one launch, no idle gap between the two
     const int nsb = (MODE == 2) ? p.n_split_blocks : 0;
@@ -516,63 +524,98 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     {
-        unsigned* sMask = reinterpret_cast<unsigned*>(smem + BIG_LDS - 16);
         const int taps = p.R * p.S;
         // DMA role: one wave-instruction = 8 rows x 128 B; per half tile a thread fetches rows rr and rr+64
         const int rr = wave * 8 + (lane >> 3);
         const int gchunk = (lane & 7) ^ ((rr >> 1) & 7);    // XOR swizzle on the SOURCE chunk (LDS image is lane-linear)
         // pixel rows [h][q] -> block pixel q*128 + h*64 + rr;  cout rows [i][q] -> ((rr>>5) + 2q)*64 + i*32 + (rr&31)
-        int hb[4], wb[4], nb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int m = m0 + (k & 1) * 128 + (k >> 1) * 64 + rr;
-            if (m < p.M) {
-                const int n = m / p.HWout;
-                const int rem = m - n * p.HWout;
-                const int ho = rem / p.Wout;
-                const int wo = rem - ho * p.Wout;
-                hb[k] = ho * p.smul + p.off_h;
-                wb[k] = wo * p.smul + p.off_w;
-                nb[k] = n * p.Hin * p.Win;
-            } else {
-                hb[k] = -(1 << 28); wb[k] = -(1 << 28); nb[k] = 0;
-            }
-        }
-        if (tid == 0) *sMask = 0u;
-        __syncthreads();
+        // p.pointwise (1x1, stride 1, no padding: the source pixel IS the output pixel) needs no coordinates at all;
+        // otherwise one division pair per thread, the other three rows (+64, +128, +192 pixels) follow by carries
+        int baseA[4];
         unsigned vmask[4] = {0u, 0u, 0u, 0u};
-        {
-            int t = 0;
-            for (int r = 0; r < p.R; ++r)
-                for (int s = 0; s < p.S; ++s, ++t) {
+        unsigned tapmask = 1u;
+        if (p.pointwise) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int hi = hb[k] + r * p.tstep_h, wi = wb[k] + s * p.tstep_w;
-                        if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) vmask[k] |= 1u << t;
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + (k & 1) * 128 + (k >> 1) * 64 + rr;
+                vmask[k] = m < p.M ? 1u : 0u;
+                baseA[k] = m * p.Cin * 2 + gchunk * 16;
+            }
+        } else {
+            unsigned* sMask = reinterpret_cast<unsigned*>(smem + BIG_LDS - 16);
+            if (tid == 0) *sMask = 0u;
+            int hb[4], wb[4], nb[4];
+            {
+                const int mA = m0 + rr;
+                int n = mA / p.HWout;
+                const int rem = mA - n * p.HWout;
+                int ho = rem / p.Wout;
+                int wo = rem - ho * p.Wout;
+                const bool carry_ok = p.Wout >= 64;           // +64 pixels wraps at most one row (else: divide again)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {              // rows in pixel order: k = 0, 2, 1, 3
+                    const int k = (kk >> 1) | ((kk & 1) << 1);
+                    if (kk > 0) {
+                        if (carry_ok) {
+                            wo += 64;
+                            if (wo >= p.Wout) { wo -= p.Wout; ++ho; }
+                            if (ho >= p.Hout) { ho -= p.Hout; ++n; }
+                        } else {
+                            const int m = mA + kk * 64;
+                            n = m / p.HWout;
+                            const int r2 = m - n * p.HWout;
+                            ho = r2 / p.Wout;
+                            wo = r2 - ho * p.Wout;
+                        }
+                    }
+                    if (mA + kk * 64 < p.M) {
+                        hb[k] = ho * p.smul + p.off_h;
+                        wb[k] = wo * p.smul + p.off_w;
+                        nb[k] = n * p.Hin * p.Win;
+                    } else {
+                        hb[k] = -(1 << 28); wb[k] = -(1 << 28); nb[k] = 0;
                     }
                 }
+            }
+            __syncthreads();
+            // tap (r, s) is visible from a row iff r is visible along h and s along w: R + S range checks per row
+            {
+                unsigned hm[4] = {0u, 0u, 0u, 0u}, wm[4] = {0u, 0u, 0u, 0u};
+                for (int r = 0; r < p.R; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((unsigned)(hb[k] + r * p.tstep_h) < (unsigned)p.Hin) hm[k] |= 1u << r;
+                for (int s = 0; s < p.S; ++s)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((unsigned)(wb[k] + s * p.tstep_w) < (unsigned)p.Win) wm[k] |= 1u << s;
+                for (int r = 0; r < p.R; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((hm[k] >> r) & 1u) vmask[k] |= wm[k] << (r * p.S);
+            }
             unsigned mine = vmask[0] | vmask[1] | vmask[2] | vmask[3];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
             if (lane == 0 && mine) atomicOr(sMask, mine);
+            __syncthreads();
+            tapmask = *sMask;
+            __syncthreads();                   // sMask lies inside the epilogue staging area
+#pragma unroll
+            for (int k = 0; k < 4; ++k) baseA[k] = ((nb[k] + hb[k] * p.Win + wb[k]) * p.Cin) * 2 + gchunk * 16;
         }
-        __syncthreads();
-        const unsigned tapmask = *sMask;
         const int kc_steps = p.Cin / 64;
         const int nk_all = __popc(tapmask) * kc_steps;
         const int k_begin = split_blk ? (int)((long long)split * nk_all / nsplit) : 0;
         const int k_end = split_blk ? (int)((long long)(split + 1) * nk_all / nsplit) : nk_all;
         const int nk = k_end - k_begin;
-        __syncthreads();                   // sMask lies inside the epilogue staging area
 
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
 
-        int baseA[4];
         uint32_t voffA[4], voffW[4], voffWl[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            baseA[k] = ((nb[k] + hb[k] * p.Win + wb[k]) * p.Cin) * 2 + gchunk * 16;
             const int co = n0 + ((rr >> 5) + 2 * (k & 1)) * 64 + (k >> 1) * 32 + (rr & 31);
             voffW[k] = (co < p.Cout) ? (uint32_t)((co * taps * p.Cin) * 2 + gchunk * 16) : EESEG_OOB;
             voffA[k] = EESEG_OOB; voffWl[k] = EESEG_OOB;
@@ -750,28 +793,26 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     }
 
     // ---- epilogue 1: acc -> (scale, shift) -> LDS staging [pixel][cout] --------
+    // (this kernel only runs layers with Cout % 256 == 0 and 16-byte row stores: no column guards, no scalar tails)
     char* stage = smem;
     float* sRed = reinterpret_cast<float*>(smem + BIGT * BIG_SROW);   // [8 waves][2][256]
+    const bool affine = p.scale != nullptr || p.shift != nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cl = wc * 64 + i * 32 + 8 * g + 4 * fh;
-            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = n0 + cl + e;
-                if (co < p.Cout) {
-                    if (p.scale) sc[e] = p.scale[co];
-                    if (p.shift) sh[e] = p.shift[co];
-                }
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (affine) {
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + cl);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n0 + cl);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int px = wp * 128 + j * 32 + fr;
                 T v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][j][4 * g + e] * sc[e] + sh[e]);
+                for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(affine ? acc[i][j][4 * g + e] * sc[e] + sh[e] : acc[i][j][4 * g + e]);
                 // 8-byte XOR on rows 8..15 (mod 16): lanes fr and fr+8 of a 16-lane store group would share banks
                 *reinterpret_cast<bf16x4*>(stage + px * BIG_SROW + ((cl * 2) ^ (((px >> 3) & 1) << 3))) = bf16x4{v[0], v[1], v[2], v[3]};
             }
@@ -787,7 +828,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     T* yout = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.residual);
-    const bool full = p.vec_ok && (cg + 8 <= p.Cout);
+    const bool post = res != nullptr || p.relu;            // block-uniform: the training forward has neither
     i32x4 rq[16];
 #pragma unroll
     for (int it = 0; it < 16; ++it) {                      // all LDS reads first (the accumulators are dead: registers are free)
@@ -795,45 +836,62 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         const i32x4 q = *reinterpret_cast<const i32x4*>(stage + row * BIG_SROW + c * 16);
         rq[it] = ((row >> 3) & 1) ? i32x4{q[2], q[3], q[0], q[1]} : q;
     }
+    if (post) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int row = r0 + 16 * it;
-        const int m = m0 + row;
-        if (m < p.M) {
-            union { i32x4 q; T e[8]; } u;
-            u.q = rq[it];
-            T* v = u.e;
-            if (res != nullptr) {
-                if (full) {
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + r0 + 16 * it;
+            if (m < p.M) {
+                union { i32x4 q; T e[8]; } u;
+                u.q = rq[it];
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = to_f32(u.e[e]);
+                if (res != nullptr) {
                     union { i32x4 q; T e[8]; } ur;
                     ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
-                } else {
+                    for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(ur.e[e])));
+                }
+                if (p.relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (cg + e < p.Cout) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(res[(size_t)m * p.ldres + cg + e]));
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u.e[e] = from_f32<T>(f[e]);
+                rq[it] = u.q;
+            }
+        }
+    }
+    // the stores first (they drain while the statistics are summed), one 64-bit pointer bump per row
+    {
+        T* yrow = yout + (size_t)(m0 + r0) * p.ldy + cg;
+        const size_t ystep = (size_t)16 * p.ldy;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (m0 + r0 + 16 * it < p.M) *reinterpret_cast<i32x4*>(yrow) = rq[it];
+            yrow += ystep;
+        }
+    }
+    if (p.stats) {                                         // of the values as stored (bf16); packed fp32 math, 2 couts per op
+        f32x2 a1[4], a2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (m0 + r0 + 16 * it < p.M) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w = (unsigned)rq[it][k];
+                    const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                    a1[k] += f;
+                    a2[k] += f * f;
                 }
             }
-            if (p.relu) {
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(fmaxf(to_f32(v[e]), 0.f));
-            }
-            if (p.stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = to_f32(v[e]);
-                    s1[e] += f;
-                    s2[e] += f * f;
-                }
-            }
-            if (full) {
-                *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = u.q;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (cg + e < p.Cout) yout[(size_t)m * p.ldy + cg + e] = v[e];
-            }
+        for (int k = 0; k < 4; ++k) {
+            s1[2 * k] = a1[k][0]; s1[2 * k + 1] = a1[k][1];
+            s2[2 * k] = a2[k][0]; s2[2 * k + 1] = a2[k][1];
         }
     }
     if (p.stats) {
@@ -854,11 +912,9 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) t += sRed[(w * 2 + which) * BIGT + col];
-        if (n0 + col < p.Cout) {
-            // the partial-sum buffer has one row pair per 128 pixels (eeseg_conv_stats_tiles): this tile owns two
-            p.stats[((size_t)(2 * mt) * 2 + which) * p.Cout + n0 + col] = t;
-            if (2 * mt + 1 < p.m_tiles) p.stats[((size_t)(2 * mt + 1) * 2 + which) * p.Cout + n0 + col] = 0.f;
-        }
+        // the partial-sum buffer has one row pair per 128 pixels (eeseg_conv_stats_tiles): this tile owns two
+        p.stats[((size_t)(2 * mt) * 2 + which) * p.Cout + n0 + col] = t;
+        if (2 * mt + 1 < p.m_tiles) p.stats[((size_t)(2 * mt + 1) * 2 + which) * p.Cout + n0 + col] = 0.f;
     }
 }
 
@@ -981,6 +1037,8 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     }
 }
 
+int g_conv_big_skew = 0;         // EESEG_OPT_CONV_SKEW: start delay in 10-ns ticks (0 = off)
+int g_conv_big_skew_nk = 16;     // ... for layers with at most this many K tiles per output tile
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
 
@@ -989,6 +1047,7 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     const int tiles = (int)((M + BIGT - 1) / BIGT) * p.n_tiles;
     const int rounds = tiles / 256, rem = tiles % 256;
     const int nk_max = p.R * p.S * (p.Cin / 64);
+    p.skew = (rounds >= 3 && nk_max <= g_conv_big_skew_nk) ? g_conv_big_skew : 0;
     int ksplit = 1;
     if (rem > 0 && rem < g_conv_big_tail_min) {
         ksplit = 256 / rem;
@@ -1061,6 +1120,14 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_narrow_max = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_SKEW && value >= 0 && value <= 10000) {
+        g_conv_big_skew = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_SKEW_NK && value >= 0 && value <= 4096) {
+        g_conv_big_skew_nk = value;
+        return EESEG_OK;
+    }
     if (key == EESEG_OPT_CONV_TAIL_MERGE && (value == 0 || value == 1)) {
         g_conv_big_merge = value;
         return EESEG_OK;
@@ -1090,6 +1157,8 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_TAIL_MIN: return g_conv_big_tail_min;
         case EESEG_OPT_CE_SPAN: return g_ce_span;
         case EESEG_OPT_CONV_TAIL_MERGE: return g_conv_big_merge;
+        case EESEG_OPT_CONV_SKEW: return g_conv_big_skew;
+        case EESEG_OPT_CONV_SKEW_NK: return g_conv_big_skew_nk;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1139,11 +1208,14 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
-    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0;
+    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.skew = 0; p.pointwise = 0;
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;
-    if (g_conv_pipe == 3 && a->dtype == EESEG_BF16 && a->sdiv == 1 && a->Cout % BIGT == 0) {
+    const bool affine_ok = (((uintptr_t)a->scale | (uintptr_t)a->shift) & 15) == 0;
+    if (g_conv_pipe == 3 && a->dtype == EESEG_BF16 && a->sdiv == 1 && a->Cout % BIGT == 0 && p.vec_ok && affine_ok) {
+        p.pointwise = a->R * a->S == 1 && a->smul == 1 && a->off_h == 0 && a->off_w == 0 && a->Hin == a->Hout &&
+                      a->Win == a->Wout;
         p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
         return launch_big(p, M, st, a->workspace, a->workspace_bytes);
     }

@@ -40,7 +40,9 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_CONV_TAIL_MERGE = 7 /* 256x256 kernel: K-split tail blocks and full rounds in ONE launch (default 1) */,
+enum { EESEG_OPT_CONV_SKEW = 8 /* 256x256 kernel, layers of >= 3 rounds and few K tiles: start delay (10-ns ticks) of half of the first-round blocks (default 0 = off) */,
+       EESEG_OPT_CONV_SKEW_NK = 9 /* ... applies to layers with at most this many K tiles per output tile (default 16) */,
+       EESEG_OPT_CONV_TAIL_MERGE = 7 /* 256x256 kernel: K-split tail blocks and full rounds in ONE launch (default 1) */,
        EESEG_OPT_CE_SPAN = 6 /* fused cross entropy: 1 = one thread per span (default), 0 = one half wave per pixel */,
        EESEG_OPT_CONV_TAIL_MIN = 5 /* 256x256 kernel: a last round with fewer tiles than this is split along K (default 224; 0 = never) */,
        EESEG_OPT_CONV_AUTO_NARROW = 4 /* 1: 128x64 tiles when the 128x128 grid underfills the chip (default 0) */,

@@ -47,11 +47,14 @@ def _run(distributed, steps=4):
     return np.array(losses)
 
 
-def test_rccl_collectives_in_graph_match_local_run(monkeypatch):
+def _child():
+    """Body of the rehearsal, run in a process of its own (see the test below); prints one JSON line."""
+    import json
     base = _run(False)
-    monkeypatch.setenv("EESEG_FORCE_ALLREDUCE", "1")
+    os.environ["EESEG_FORCE_ALLREDUCE"] = "1"
     dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}",
                             device_id=torch.device("cuda", 0))
+    print("RCCL_INIT_OK", flush=True)
     try:
         got = _run(True)
     finally:
@@ -59,10 +62,39 @@ def test_rccl_collectives_in_graph_match_local_run(monkeypatch):
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        dist.destroy_process_group()
+    print("RESULT " + json.dumps({"base": base.tolist(), "got": got.tolist()}), flush=True)
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_in_graph_match_local_run():
+    # In a child process: RCCL aborts the whole process when its bootstrap fails on a box (seen as a core dump inside
+    # init_process_group / destroy_process_group, before or after any of this package's code runs); the pytest
+    # process, and the GPU tests after this one, must survive that.  Only a failure to bring the communicator up is
+    # tolerated (skip); everything after "RCCL_INIT_OK" is this package's code and must pass.
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("EESEG_FORCE_ALLREDUCE", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True,
+                       timeout=420)
+    if "RCCL_INIT_OK" not in r.stdout:
+        assert "RESULT" not in r.stdout
+        if r.returncode < 0 or "NCCL" in r.stderr or "RCCL" in r.stderr:
+            pytest.skip(f"RCCL communicator bootstrap failed on this box (rc={r.returncode}): {r.stderr[-300:]}")
+        raise AssertionError(f"rehearsal child failed before RCCL init (rc={r.returncode}):\n{r.stderr[-2000:]}")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert lines, f"rehearsal child died after RCCL init (rc={r.returncode}):\n{r.stderr[-2000:]}"
+    res = json.loads(lines[0][len("RESULT "):])
+    base, got = np.array(res["base"]), np.array(res["got"])
     assert np.all(np.isfinite(got))
     # same dropout seeds, same data: the first step agrees to fp32 rounding; the SyncBN path sums the
     # BN partials in a different order than the fused local kernel (1-ulp statistics), so from the second
     # step on the runs sit inside the chaos band of DESIGN.md section 5
     assert abs(got[0] - base[0]) < 1e-5 * abs(base[0])
     assert np.all(np.abs(got - base) < 2e-2 * np.abs(base)), (base.tolist(), got.tolist())
+
+
+if __name__ == "__main__" and "--child" in __import__("sys").argv:
+    __import__("sys").path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _child()
