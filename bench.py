@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--classes", type=int, default=21)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="N>1: CUs the conv launch plans leave to RCCL while gradient buckets are in flight (default: "
+                         "EESEG_RCCL_RESERVE_CUS or 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no HIP-graph replay)")
@@ -165,7 +168,7 @@ def main():
                {"params": net.branches.parameters(), "lr": lr},
                {"params": net.classifier.parameters(), "lr": lr * 1.1}], lr=lr, momentum=0.9, weight_decay=5e-4)
     net.enable_grad_arena()
-    reducer = ArenaReducer(net)
+    reducer = ArenaReducer(net, reserve_cus=args.reserve_cus)
     X, y = synth_batch(B, C, img, img, 1234 + rank, dev)
     net.train()
     # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a

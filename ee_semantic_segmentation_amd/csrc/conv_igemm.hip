@@ -35,7 +35,6 @@ struct ConvP {
     int n_split_blocks;       // MODE 2: leading blocks that work on K ranges of the tail tiles
     float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
     int pointwise;            // 256x256 kernel: 1x1, stride 1, no padding (source pixel = output pixel)
-    int skew;                 // 256x256 kernel: start delay (10-ns ticks) of every other group of 8 first-round blocks
 };
 
 template <typename T> struct Mma;
@@ -494,12 +493,6 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // short-K layers run load / MFMA / store phases in lock step on all CUs and each phase then queues on HBM: delaying
-    // half of the first-round blocks (one group of 8 = one block per XCD in two) puts the two halves in opposite phases
-    if (p.skew > 0 && (int)blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)p.skew) __builtin_amdgcn_s_sleep(32);
-    }
     // MODE 2 (mixed launch): the first p.n_split_blocks blocks are K ranges of the tail tiles (they are dispatched
     // first and finish early), the others are whole tiles 0 .. p.tile_begin-1 - one launch, no idle gap between the two
     const int nsb = (MODE == 2) ? p.n_split_blocks : 0;
@@ -1037,20 +1030,19 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     }
 }
 
-int g_conv_big_skew = 0;         // EESEG_OPT_CONV_SKEW: start delay in 10-ns ticks (0 = off)
-int g_conv_big_skew_nk = 16;     // ... for layers with at most this many K tiles per output tile
+int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
 
-// launch plan for the 256x256 kernel: full rounds of 256 tiles, then the remainder split along K
+// launch plan for the 256x256 kernel: full rounds of one tile per available CU, then the remainder split along K
 int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long workspace_bytes) {
     const int tiles = (int)((M + BIGT - 1) / BIGT) * p.n_tiles;
-    const int rounds = tiles / 256, rem = tiles % 256;
+    const int cus = g_conv_big_cus;
+    const int rounds = tiles / cus, rem = tiles % cus;
     const int nk_max = p.R * p.S * (p.Cin / 64);
-    p.skew = (rounds >= 3 && nk_max <= g_conv_big_skew_nk) ? g_conv_big_skew : 0;
     int ksplit = 1;
-    if (rem > 0 && rem < g_conv_big_tail_min) {
-        ksplit = 256 / rem;
+    if (rem > 0 && rem < g_conv_big_tail_min * cus / 256) {
+        ksplit = cus / rem;
         if (ksplit > nk_max / 4) ksplit = nk_max / 4;            // at least 4 K tiles per range (pipeline fill)
         const long long fit = workspace ? workspace_bytes / ((long long)rem * SLAB_FLOATS * 4) : 0;
         if (ksplit > fit) ksplit = (int)fit;
@@ -1063,15 +1055,15 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     }
     p.slabs = reinterpret_cast<float*>(workspace);
     p.ksplit = ksplit;
-    p.tile_begin = rounds * 256;
+    p.tile_begin = rounds * cus;
     p.n_split_blocks = rem * ksplit;
     if (rounds > 0 && g_conv_big_merge)        // one launch: K-range blocks first, whole tiles behind them
-        hipLaunchKernelGGL(conv_big_kernel<2>, dim3(rem * ksplit + rounds * 256), dim3(512), 0, st, p);
+        hipLaunchKernelGGL(conv_big_kernel<2>, dim3(rem * ksplit + rounds * cus), dim3(512), 0, st, p);
     else {
         if (rounds > 0) {
             ConvP q = p;
             q.tile_begin = 0;
-            hipLaunchKernelGGL(conv_big_kernel<0>, dim3(rounds * 256), dim3(512), 0, st, q);
+            hipLaunchKernelGGL(conv_big_kernel<0>, dim3(rounds * cus), dim3(512), 0, st, q);
         }
         hipLaunchKernelGGL(conv_big_kernel<1>, dim3(rem * ksplit), dim3(512), 0, st, p);
     }
@@ -1120,12 +1112,8 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_narrow_max = value;
         return EESEG_OK;
     }
-    if (key == EESEG_OPT_CONV_SKEW && value >= 0 && value <= 10000) {
-        g_conv_big_skew = value;
-        return EESEG_OK;
-    }
-    if (key == EESEG_OPT_CONV_SKEW_NK && value >= 0 && value <= 4096) {
-        g_conv_big_skew_nk = value;
+    if (key == EESEG_OPT_CONV_CUS && value >= 32 && value <= 256) {
+        g_conv_big_cus = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_CONV_TAIL_MERGE && (value == 0 || value == 1)) {
@@ -1157,8 +1145,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_TAIL_MIN: return g_conv_big_tail_min;
         case EESEG_OPT_CE_SPAN: return g_ce_span;
         case EESEG_OPT_CONV_TAIL_MERGE: return g_conv_big_merge;
-        case EESEG_OPT_CONV_SKEW: return g_conv_big_skew;
-        case EESEG_OPT_CONV_SKEW_NK: return g_conv_big_skew_nk;
+        case EESEG_OPT_CONV_CUS: return g_conv_big_cus;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1208,7 +1195,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
-    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.skew = 0; p.pointwise = 0;
+    p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.pointwise = 0;
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;

@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, cons
     const long long rb = (long long)blockIdx.y * rows_per_block;
     const long long re = rb + rows_per_block < rows ? rb + rows_per_block : rows;
     const int c0t = (blockIdx.x * TX + (threadIdx.x % TX)) * EPC;
-    // relu: 0 none, 1 mask from y > 0, 2 mask recomputed as x*scale+shift > 0 (no y read)
+    // relu: 0 none, 1 mask from y > 0, 2 mask recomputed as x*scale+shift > 0 (no y read), 3 byte mask written by
+    // bn_apply (y = mask, one byte per 16-byte chunk, ldy = bytes per row)
+    const unsigned char* bmask = reinterpret_cast<const unsigned char*>(y);
     float mu[EPC], is[EPC], msc[EPC], msh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -258,12 +260,15 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, cons
             Vec<T> g = ld16(dy + r * lddy + c0);
             Vec<T> xv = ld16(x + r * ldx + c0);
             Vec<T> yv;
+            unsigned mb = 0u;
             if (relu == 1) yv = ld16(y + r * ldy + c0);
+            if (relu == 3) mb = bmask[r * ldy + c0 / EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 float gf = to_f32(g.e[e]);
                 const float xf = to_f32(xv.e[e]);
                 if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+                if (relu == 3 && !((mb >> e) & 1u)) gf = 0.f;
                 if (relu == 2 && !(xf * msc[e] + msh[e] > 0.f)) gf = 0.f;   // sign survives the bf16 rounding
                 const float xh = (xf - mu[e]) * is[e];
                 acc[0][e] += gf;
@@ -394,7 +399,7 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
-                                                       int C, int relu) {
+                                                       int C, int relu, unsigned char* mask) {
     constexpr int EPC = 16 / (int)sizeof(TI);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -422,6 +427,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
 #pragma unroll
             for (int e = 0; e < EPC; ++e) w.e[e] = from_f32<TO>(o[e]);
             st16(dst, w);
+            if (mask) {        // one byte per 16-byte chunk: bit e = (stored y[e] > 0), the ReLU mask of the backward
+                unsigned m = 0u;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m |= (to_f32(w.e[e]) > 0.f ? 1u : 0u) << e;
+                mask[r * cpr + c0 / EPC] = (unsigned char)m;
+            }
         } else {   // bf16 in (8 elems) -> f32 out: two 16-byte stores
             Vec<TO> w0, w1;
 #pragma unroll
@@ -448,6 +459,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     const long long rstep = T_ / cpr;
     // dx = ka*g + kb*(x - mean) + kc   (MODE 0: ka = gamma*invstd, kb = -ka*invstd*s1/n, kc = -ka*s0/n)
     float ka[EPC], kb[EPC], kc[EPC], km[EPC], msc[EPC], msh[EPC];
+    const unsigned char* bmask = reinterpret_cast<const unsigned char*>(y);     // relu == 3: byte mask, ldy bytes per row
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const int c = c0 + e;
@@ -467,13 +479,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     for (long long r = gid / cpr; r < rows; r += rstep) {
         Vec<T> g = ld16(dy + r * lddy + c0);
         Vec<T> yv, xv;
+        unsigned mb = 0u;
         if (relu == 1) yv = ld16(y + r * ldy + c0);
+        if (relu == 3) mb = bmask[r * ldy + c0 / EPC];
         if (MODE == 0) xv = ld16(x + r * ldx + c0);
         Vec<T> od, og;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float gf = to_f32(g.e[e]);
             if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+            if (relu == 3 && !((mb >> e) & 1u)) gf = 0.f;
             if (MODE == 0 && relu == 2 && !(to_f32(xv.e[e]) * msc[e] + msh[e] > 0.f)) gf = 0.f;
             og.e[e] = from_f32<T>(gf);
             float d = ka[e] * gf;
@@ -985,31 +1000,45 @@ extern "C" int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, 
     return EESEG_OK;
 }
 
-extern "C" int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
-                              void* y, int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype,
-                              void* stream) {
+static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres, void* y,
+                         int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype, unsigned char* mask,
+                         void* stream) {
     EESEG_CHECK(x && y && scale_shift && rows > 0, EESEG_ERR_ARG, "bn_apply: bad argument");
     CHECK_ROWS("bn_apply x", x, ldx, C, in_dtype);
     if (residual) CHECK_ROWS("bn_apply residual", residual, ldres, C, in_dtype);
     EESEG_CHECK(((uintptr_t)y & 15) == 0 && ldy >= C && ldy % 4 == 0, EESEG_ERR_ARG, "bn_apply: bad y/ldy");
+    EESEG_CHECK(!mask || in_dtype == out_dtype, EESEG_ERR_ARG, "bn_apply: the ReLU mask needs equal in/out dtypes");
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(in_dtype);
     const int g = colfixed_grid(rows, C / epc);
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu);
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask);
     } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu);
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask);
     } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
         hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu);
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask);
     } else {
         EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
     }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
+}
+
+extern "C" int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
+                              void* y, int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype,
+                              void* stream) {
+    return bn_apply_impl(x, ldx, scale_shift, residual, ldres, y, ldy, rows, C, relu, in_dtype, out_dtype, nullptr, stream);
+}
+
+extern "C" int eeseg_bn_apply_relu_mask(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
+                                        void* y, int ldy, void* relu_mask, int64_t rows, int C, int dtype, void* stream) {
+    EESEG_CHECK(relu_mask, EESEG_ERR_ARG, "bn_apply_relu_mask: null mask");
+    return bn_apply_impl(x, ldx, scale_shift, residual, ldres, y, ldy, rows, C, 1, dtype, dtype, (unsigned char*)relu_mask,
+                         stream);
 }
 
 // launches stage1 via `launch1(grid, rows_per_block, TX, partial_ptr)` then stage 2 when needed
@@ -1073,8 +1102,9 @@ extern "C" int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* 
 extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                    const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
                                    float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
-    EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && (relu != 1 || y) && (relu != 2 || scale_shift) &&
-                    relu >= 0 && relu <= 2, EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
+    EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && ((relu != 1 && relu != 3) || y) && (relu != 2 || scale_shift) &&
+                    relu >= 0 && relu <= 3, EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
+    EESEG_CHECK(relu != 3 || ldy >= C / (16 / eeseg_dtype_size(dtype)), EESEG_ERR_ARG, "bn_bwd_reduce: mask row too short");
     CHECK_ROWS("bn_bwd_reduce dy", dy, lddy, C, dtype);
     CHECK_ROWS("bn_bwd_reduce x", x, ldx, C, dtype);
     if (relu == 1) CHECK_ROWS("bn_bwd_reduce y", y, ldy, C, dtype);
@@ -1094,8 +1124,9 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                                   const float* mean_invstd, const float* gamma, const float* sums, double count,
                                   void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu,
                                   const float* scale_shift, int dtype, void* stream) {
-    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && (relu != 1 || y) &&
-                    (relu != 2 || scale_shift) && relu >= 0 && relu <= 2, EESEG_ERR_ARG, "bn_bwd_apply: bad argument");
+    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && ((relu != 1 && relu != 3) || y) &&
+                    (relu != 2 || scale_shift) && relu >= 0 && relu <= 3, EESEG_ERR_ARG, "bn_bwd_apply: bad argument");
+    EESEG_CHECK(relu != 3 || ldy >= C / (16 / eeseg_dtype_size(dtype)), EESEG_ERR_ARG, "bn_bwd_apply: mask row too short");
     CHECK_ROWS("bn_bwd_apply dy", dy, lddy, C, dtype);
     CHECK_ROWS("bn_bwd_apply x", x, ldx, C, dtype);
     CHECK_ROWS("bn_bwd_apply dx", dx, lddx, C, dtype);

@@ -271,10 +271,13 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
     else:       # local BatchNorm: partial reduction and finalize fused in one launch
         mi, ss = K.bn_reduce_finalize(part, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
     bn._pending_batches += 1
+    # backward recomputes the ReLU mask from c*scale+shift when there is no residual input (saves streaming y
+    # again); with a residual the forward leaves a byte mask (1 bit per element) as the mask source
+    if residual is not None and relu:
+        y, mask = K.bn_apply(c, ss, residual=residual, relu=True, out=out, want_mask=True)
+        return y, (x, c, mask, mi, count, relu, ss)
     y = K.bn_apply(c, ss, residual=residual, relu=relu, out=out)
-    # backward recomputes the ReLU mask from c*scale+shift when there is no residual input
-    # (saves streaming y again); with a residual the stored output is the mask source
-    return y, (x, c, y if residual is not None else None, mi, count, relu, ss)
+    return y, (x, c, None, mi, count, relu, ss)
 
 
 def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):

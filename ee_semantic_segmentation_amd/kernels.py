@@ -316,7 +316,9 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
     return ss
 
 
-def bn_apply(x, scale_shift, *, residual=None, relu=False, out=None, out_dtype=None):
+def bn_apply(x, scale_shift, *, residual=None, relu=False, out=None, out_dtype=None, want_mask=False):
+    """y = act(x*scale + shift (+ residual)).  want_mask (needs relu): also returns the ReLU byte mask
+    [rows, C/epc] uint8 the backward reads instead of y (eeseg_bn_apply_relu_mask)."""
     _need_cuda(x)
     rows, Cc, ldx = rows_ld(x)
     od = out_dtype or x.dtype
@@ -328,6 +330,12 @@ def bn_apply(x, scale_shift, *, residual=None, relu=False, out=None, out_dtype=N
     if residual is not None:
         assert residual.shape == x.shape and residual.dtype == x.dtype
         _, _, ldres = rows_ld(residual)
+    if want_mask:
+        assert relu and out.dtype == x.dtype
+        mask = torch.empty((rows, Cc // (16 // x.element_size())), dtype=torch.uint8, device=x.device)
+        check(lib().eeseg_bn_apply_relu_mask(_p(x), ldx, _p(scale_shift), _p(residual), ldres, _p(out), ldy, _p(mask),
+                                             rows, Cc, _dt(x), _stream()), "eeseg_bn_apply_relu_mask")
+        return out, mask
     check(lib().eeseg_bn_apply(_p(x), ldx, _p(scale_shift), _p(residual), ldres, _p(out), ldy, rows, Cc, int(relu),
                                _dt(x), _dt(out), _stream()), "eeseg_bn_apply")
     return out
@@ -354,9 +362,11 @@ def colsum(x, out=None):
 
 
 def _relu_mode(relu, y, scale_shift):
-    """0 none / 1 mask from stored y / 2 mask recomputed from x*scale+shift (no y read)."""
+    """0 none / 1 mask from stored y / 2 mask recomputed from x*scale+shift (no y read) / 3 byte mask of bn_apply."""
     if not relu:
         return 0
+    if y is not None and y.dtype == torch.uint8:
+        return 3
     return 2 if (y is None and scale_shift is not None) else 1
 
 

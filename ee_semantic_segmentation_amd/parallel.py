@@ -111,8 +111,13 @@ class ArenaReducer:
     last unit it covers has finished its backward, overlapping with the rest of
     backward.  No flatten / unflatten copies."""
 
-    def __init__(self, net, bucket_bytes=64 << 20, group=None, average=True):
+    def __init__(self, net, bucket_bytes=64 << 20, group=None, average=True, reserve_cus=None):
         self.cfg, self.group, self.average = net.cfg, group, average
+        # CUs left to the RCCL kernels while buckets are in flight: the 256-tile conv kernels run one block per CU and
+        # size their rounds / K splits for the CUs they can get, so a launch planned for 256 CUs needs a second round
+        # when a collective holds a few of them.  0 = plan for the whole chip (default; EESEG_RCCL_RESERVE_CUS).
+        self.reserve_cus = int(os.environ.get("EESEG_RCCL_RESERVE_CUS", "0")) if reserve_cus is None else reserve_cus
+        self._reserved = False
         self.arena = net.cfg.arena
         if self.arena is None:
             raise RuntimeError("call net.enable_grad_arena() first")
@@ -141,7 +146,15 @@ class ArenaReducer:
             self._launch(a, b)
             self._next += 1
 
+    def _plan_cus(self, cus):
+        from ._lib import lib
+        lib().eeseg_set_option(8, cus)                    # EESEG_OPT_CONV_CUS
+        lib().eeseg_set_wgrad_big_grid(cus, 8)
+
     def _launch(self, a, b):
+        if self.reserve_cus > 0 and not self._reserved:
+            self._plan_cus(256 - self.reserve_cus)
+            self._reserved = True
         seg = self.arena.flat[a:b]
         nccl = dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
@@ -158,6 +171,9 @@ class ArenaReducer:
             work.wait()
             if self.average and op == dist.ReduceOp.SUM:
                 seg.div_(self.world)
+        if self._reserved:
+            self._plan_cus(256)
+            self._reserved = False
         self._done.clear()
         self._next = 0
         self._works = []
@@ -211,7 +227,10 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                # thread_local: the RCCL watchdog thread keeps polling the events of the warm-up steps' collectives
+                # (hipEventQuery); under the default global capture mode such a poll during the capture is an error
+                # that aborts the process
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self.loss = self._eager(self.X, self.y)
             except Exception as exc:                # e.g. a collective that cannot be captured
                 import warnings

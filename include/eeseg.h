@@ -40,8 +40,7 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_CONV_SKEW = 8 /* 256x256 kernel, layers of >= 3 rounds and few K tiles: start delay (10-ns ticks) of half of the first-round blocks (default 0 = off) */,
-       EESEG_OPT_CONV_SKEW_NK = 9 /* ... applies to layers with at most this many K tiles per output tile (default 16) */,
+enum { EESEG_OPT_CONV_CUS = 8 /* 256x256 conv kernel: CUs a launch may count on when it sizes its rounds and its K-split tail (default 256; lower it while collectives hold CUs) */,
        EESEG_OPT_CONV_TAIL_MERGE = 7 /* 256x256 kernel: K-split tail blocks and full rounds in ONE launch (default 1) */,
        EESEG_OPT_CE_SPAN = 6 /* fused cross entropy: 1 = one thread per span (default), 0 = one half wave per pixel */,
        EESEG_OPT_CONV_TAIL_MIN = 5 /* 256x256 kernel: a last round with fewer tiles than this is split along K (default 224; 0 = never) */,
@@ -158,6 +157,11 @@ int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, const float
  * classifier).  rows = N*H*W. */
 int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
                    void* y, int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype, void* stream);
+/* bn_apply with relu = 1 that also writes the ReLU mask of the backward: one byte per 16-byte channel chunk
+ * (8 bf16 / 4 fp32 channels), bit e = (stored y[chunk*epc + e] > 0); relu_mask[rows][C/epc].  Layers with a
+ * residual input cannot recompute the mask from x alone: with the byte mask their backward streams 1/16 of y. */
+int eeseg_bn_apply_relu_mask(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
+                             void* y, int ldy, void* relu_mask, int64_t rows, int C, int dtype, void* stream);
 /* per-channel sums of x and x^2 over rows (tensors that did not come out of the
  * conv epilogue, e.g. the pooled ASPP branch): sums[2][C] */
 int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype, void* workspace,
@@ -165,7 +169,8 @@ int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums
 /* backward, step 1: g = dy * mask; sums[0][c] = sum g, sums[1][c] = sum g*xhat.
  * relu: 0 no activation; 1 mask = (y > 0) read from the stored output; 2 mask recomputed as
  * (x*scale+shift > 0) from scale_shift[2][C] - for layers without a residual input this saves the
- * read of y (one of the 3-4 streamed tensors). */
+ * read of y (one of the 3-4 streamed tensors); 3 `y` points at the byte mask of eeseg_bn_apply_relu_mask and
+ * `ldy` is its row length in bytes (same in eeseg_bn_bwd_apply). */
 int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                         const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
                         float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream);

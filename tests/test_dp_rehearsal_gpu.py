@@ -84,7 +84,8 @@ def test_rccl_collectives_in_graph_match_local_run():
             pytest.skip(f"RCCL communicator bootstrap failed on this box (rc={r.returncode}): {r.stderr[-300:]}")
         raise AssertionError(f"rehearsal child failed before RCCL init (rc={r.returncode}):\n{r.stderr[-2000:]}")
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert lines, f"rehearsal child died after RCCL init (rc={r.returncode}):\n{r.stderr[-2000:]}"
+    err_lines = "\n".join(l for l in r.stderr.splitlines() if "rror" in l and "frame #" not in l)[:3000]
+    assert lines, f"rehearsal child died after RCCL init (rc={r.returncode}):\n{err_lines}\n...\n{r.stderr[-1500:]}"
     res = json.loads(lines[0][len("RESULT "):])
     base, got = np.array(res["base"]), np.array(res["got"])
     assert np.all(np.isfinite(got))

@@ -167,6 +167,12 @@ def test_batchnorm_train_fwd_bwd(dtype, relu, use_res):
     close(nchw(dx), x.grad, 3e-4 if dtype == torch.float32 else 3e-2, "bn dx")
     if use_res:
         close(nchw(dres), res.grad, tol(dtype), "bn dres")
+        # byte mask written by the forward (1 bit per element) instead of the stored output: identical results
+        yd3, mask = K.bn_apply(xd, ss, residual=resd, relu=True, want_mask=True)
+        assert torch.equal(yd3, yd) and mask.dtype == torch.uint8 and mask.shape == (cnt, Cc // (16 // xd.element_size()))
+        bs3 = K.bn_bwd_reduce(gyd, mask, xd, mi, relu)
+        dx3, dres3 = K.bn_bwd_apply(gyd, mask, xd, mi, gamma.detach().to(DEV), bs3, cnt, relu, want_dres=True)
+        assert torch.equal(bs3, bs) and torch.equal(dx3, dx) and torch.equal(dres3, dres)
     elif relu:      # mask recomputed from x*scale+shift instead of reading y: identical results
         bs2 = K.bn_bwd_reduce(gyd, None, xd, mi, relu, scale_shift=ss)
         dx2, _ = K.bn_bwd_apply(gyd, None, xd, mi, gamma.detach().to(DEV), bs2, cnt, relu, scale_shift=ss)
@@ -476,9 +482,11 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     res = None
     outs = {}
     try:
-        for name, pipe, tail, merge, inner in (("ref", 0, 224, 1, 0), ("big", 3, 0, 1, 0), ("split", 3, 224, 1, 0),
-                                               ("split2", 3, 224, 0, 0), ("inner", 3, 224, 1, 1)):
+        for name, pipe, tail, merge, inner, cus in (("ref", 0, 224, 1, 0, 256), ("big", 3, 0, 1, 0, 256),
+                                                    ("split", 3, 224, 1, 0, 256), ("split2", 3, 224, 0, 0, 256),
+                                                    ("inner", 3, 224, 1, 1, 256), ("cus", 3, 224, 1, 0, 120)):
             lib().eeseg_set_option(1, pipe)
+            lib().eeseg_set_option(8, cus)         # CUs the launch plan counts on (rounds / K-split tail sized for them)
             lib().eeseg_set_option(5, tail)
             lib().eeseg_set_option(7, merge)       # tail blocks in the main launch (default) or in their own
             lib().eeseg_set_option(2, inner)       # K order: taps outer (default) / taps inner
@@ -494,10 +502,13 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
         lib().eeseg_set_option(5, 224)
         lib().eeseg_set_option(7, 1)
         lib().eeseg_set_option(2, 0)
+        lib().eeseg_set_option(8, 256)
     ref = outs["ref"]
     for i, what in ((0, "y"), (2, "fused epilogue"), (3, "dgrad")):      # taps-inner K order: another summation order
         if ref[i] is not None:
             close(outs["inner"][i], ref[i], 8e-3, f"taps-inner {what}")
+            close(outs["cus"][i], ref[i], 8e-3, f"plan for 120 CUs {what}")
+    close(outs["cus"][1], ref[1], 2e-3, "plan for 120 CUs BN partial sums")
     for i in (0, 2, 3):                    # merged and separate tail launches do the same arithmetic
         if outs["split"][i] is not None:
             assert torch.equal(outs["split"][i], outs["split2"][i])
