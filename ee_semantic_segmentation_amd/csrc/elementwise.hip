@@ -5,6 +5,8 @@
 // ASPP concat buffer) are read/written in place.
 #include "eeseg_common.h"
 
+int g_bn_reverse = 0;               // EESEG_OPT_BN_REVERSE: bit 0 bn_apply, bit 1 bn_bwd_apply sweep rows from the end
+
 namespace {
 
 template <typename T> struct Vec {
@@ -399,7 +401,7 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
-                                                       int C, int relu, unsigned char* mask) {
+                                                       int C, int relu, unsigned char* mask, int rev) {
     constexpr int EPC = 16 / (int)sizeof(TI);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -409,7 +411,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
     float sc[EPC], sh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
-    for (long long r = gid / cpr; r < rows; r += rstep) {
+    for (long long r_ = gid / cpr; r_ < rows; r_ += rstep) {
+        const long long r = rev ? rows - 1 - r_ : r_;      // rev: sweep from the end (the rows the producer wrote last)
         Vec<TI> v = ld16(x + r * ldx + c0);
         Vec<TI> rv;
         if (res) rv = ld16(res + r * ldres + c0);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_count, T* dx,
                                                            int lddx, T* dres, int lddres, long long rows, int C,
-                                                           int relu, const float* __restrict__ scale_shift) {
+                                                           int relu, const float* __restrict__ scale_shift, int rev) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -476,7 +479,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
             ka[e] = gamma[c]; kb[e] = 0.f; kc[e] = 0.f; km[e] = 0.f;      // gamma := scale
         }
     }
-    for (long long r = gid / cpr; r < rows; r += rstep) {
+    for (long long r_ = gid / cpr; r_ < rows; r_ += rstep) {
+        const long long r = rev ? rows - 1 - r_ : r_;      // rev: against the direction of the reduction pass before
         Vec<T> g = ld16(dy + r * lddy + c0);
         Vec<T> yv, xv;
         unsigned mb = 0u;
@@ -1014,13 +1018,13 @@ static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask);
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask);
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
         hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask);
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else {
         EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
     }
@@ -1139,11 +1143,11 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
-                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift);
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
-                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift);
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -1163,12 +1167,12 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr);
+                           (const float*)nullptr, 0);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr);
+                           (const float*)nullptr, 0);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
