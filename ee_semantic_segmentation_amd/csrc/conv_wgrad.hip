@@ -648,15 +648,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
 }
 
 // dW[co][tap][ci] += sum over the K splits of one 256x256 tile, slabs in the producing kernel's register layout.
-// grid = tiles x 8 (one block per producing wave = 32 KiB of every slab), 256 threads.
-__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p) {
+// grid = (tiles x 8, G): one block per producing wave (= 32 KiB of every slab) and per group of splits, 256 threads.
+// G > 1 (few output tiles, many splits: tiles x 8 blocks alone would read the slabs at a fraction of the memory rate):
+// group g sums splits [g*n/G, (g+1)*n/G) into a second-level slab; a second launch with G = 1 folds those into dW.
+// Fixed summation order at both levels: bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p, const float* __restrict__ src, int nsplit,
+                                                                float* dst_slabs) {
     const int taps = p.R * p.S;
     const int tiles = p.co_tiles * p.ci_tiles * taps;
     int tl = blockIdx.x >> 3;
     const int wave = blockIdx.x & 7;
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int wc = wave & 3, wp = wave >> 2, fr = lane & 31, fh = lane >> 5;
-    const float* ws = p.slabs + (size_t)tl * 65536 + (wave * 32) * 256 + lane * 4;
+    const int G = gridDim.y, g = blockIdx.y;
+    const int s_begin = (int)((long long)g * nsplit / G), s_end = (int)((long long)(g + 1) * nsplit / G);
+    const size_t slice = (size_t)tl * 65536 + (wave * 32) * 256 + lane * 4;
+    const float* ws = src + slice;
     const int co_t = tl % p.co_tiles; tl /= p.co_tiles;
     const int ci_t = tl % p.ci_tiles;
     const int tap = tl / p.ci_tiles;
@@ -665,20 +672,26 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p) {
         const int i = (sub * 2 + ij) >> 2, j = (sub * 2 + ij) & 3;
         f32x4 a[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) a[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.splits; ++s) {
+        for (int q = 0; q < 4; ++q) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = s_begin; s < s_end; ++s) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                a[g] += *reinterpret_cast<const f32x4*>(ws + (size_t)s * tiles * 65536 + ((i * 4 + j) * 4 + g) * 256);
+            for (int q = 0; q < 4; ++q)
+                a[q] += *reinterpret_cast<const f32x4*>(ws + (size_t)s * tiles * 65536 + ((i * 4 + j) * 4 + q) * 256);
+        }
+        if (dst_slabs != nullptr) {
+            float* wd = dst_slabs + (size_t)g * tiles * 65536 + slice;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wd + ((i * 4 + j) * 4 + q) * 256) = a[q];
+            continue;
         }
         const int ci = ci_t * 256 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + fr;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int co = co_t * 256 + i * 128 + wc * 32 + k + 8 * g + 4 * fh;
+                const int co = co_t * 256 + i * 128 + wc * 32 + k + 8 * q + 4 * fh;
                 float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
-                *dst += a[g][k];
+                *dst += a[q][k];
             }
     }
 }
@@ -775,14 +788,27 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         // short K ranges (few output tiles -> many splits) leave one block per CU mostly filling and draining its
         // pipeline: measured break-even against the 128x128 kernel (2-3 blocks per CU) at ~20 K tiles per block
         if (g_wgrad_big == 2 || chunk / 64 >= g_wgrad_big_min_ktiles) {
-            const long long need = tiles * splits * 65536ll * 4;
+            // second reduce level when tiles x 8 blocks alone could not pull the slabs at the memory rate
+            long long G = 512 / (tiles * 8);
+            if (G > splits / 2) G = splits / 2;
+            if (G < 2) G = 1;
+            const long long need = tiles * (splits + (G > 1 ? G : 0)) * 65536ll * 4;
             p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
                           ? reinterpret_cast<float*>(a->workspace) : nullptr;
             if (p.q64 == 0)
                 hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
             else
                 hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
-            if (p.slabs) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8)), dim3(256), 0, st, p);
+            if (p.slabs && G > 1) {
+                float* lvl2 = p.slabs + (size_t)tiles * splits * 65536;
+                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), (unsigned)G), dim3(256), 0, st, p,
+                                   (const float*)p.slabs, (int)splits, lvl2);
+                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), 1), dim3(256), 0, st, p,
+                                   (const float*)lvl2, (int)G, (float*)nullptr);
+            } else if (p.slabs) {
+                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), 1), dim3(256), 0, st, p,
+                                   (const float*)p.slabs, (int)splits, (float*)nullptr);
+            }
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }

@@ -80,10 +80,15 @@ for shp, cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][
     tw = timeit(lambda: K.conv_wgrad(x, gy, k, k, s, p, d))
     lib().eeseg_set_wgrad_big(1)
     twb = timeit(lambda: K.conv_wgrad(x, gy, k, k, s, p, d))
+    lib().eeseg_set_wgrad_big(5); K.WGRAD_SLABS = True          # same kernel, K splits combined through slabs
+    tws = min(timeit(lambda: K.conv_wgrad(x, gy, k, k, s, p, d)) for _ in range(2))
+    lib().eeseg_set_wgrad_big(1); K.WGRAD_SLABS = False
+    twb = min(twb, timeit(lambda: K.conv_wgrad(x, gy, k, k, s, p, d)))
+    tot["ws"] += tws * cnt
     tot["w2"] += twb * cnt
     tot["f"] += tf * cnt; tot["d"] += td * cnt; tot["w"] += tw * cnt; tot["fl"] += fl * cnt
     print(f"{str(shp):42s} {cnt:3d} {fl/1e9:7.1f} | {tf*1e3:7.3f} {fl/tf/1e12:5.0f} | {td*1e3:8.3f} {fl/td/1e12:5.0f} | "
-          f"{tw*1e3:8.3f} {fl/tw/1e12:5.0f} || big: fwd {best[3][0]*1e3:7.3f} {fl/best[3][0]/1e12:5.0f}  dgrad {best[3][1]*1e3:7.3f} {fl/best[3][1]/1e12:5.0f}  wgrad {twb*1e3:7.3f} {fl/twb/1e12:5.0f} | taps-inner fwd {ti[0]*1e3:7.3f} dgrad {ti[1]*1e3:7.3f}", flush=True)
-print(f"256x256 kernel (PIPE=3) totals: fwd {tot['f2']*1e3:.2f} ms dgrad {tot['d2']*1e3:.2f} ms wgrad {tot['w2']*1e3:.2f} ms  (128-tile kernels below); taps-inner: fwd {tot['fi']*1e3:.2f} dgrad {tot['di']*1e3:.2f}")
+          f"{tw*1e3:8.3f} {fl/tw/1e12:5.0f} || big: fwd {best[3][0]*1e3:7.3f} {fl/best[3][0]/1e12:5.0f}  dgrad {best[3][1]*1e3:7.3f} {fl/best[3][1]/1e12:5.0f}  wgrad {twb*1e3:7.3f} {fl/twb/1e12:5.0f} slabs {tws*1e3:7.3f} | taps-inner fwd {ti[0]*1e3:7.3f} dgrad {ti[1]*1e3:7.3f}", flush=True)
+print(f"256x256 kernel (PIPE=3) totals: fwd {tot['f2']*1e3:.2f} ms dgrad {tot['d2']*1e3:.2f} ms wgrad {tot['w2']*1e3:.2f} ms (slabs {tot['ws']*1e3:.2f})  (128-tile kernels below); taps-inner: fwd {tot['fi']*1e3:.2f} dgrad {tot['di']*1e3:.2f}")
 print(f"TOTAL per step: fwd {tot['f']*1e3:.2f} ms ({tot['fl']/tot['f']/1e12:.0f} TF)  dgrad {tot['d']*1e3:.2f} ms "
       f"({tot['fl']/tot['d']/1e12:.0f} TF)  wgrad {tot['w']*1e3:.2f} ms ({tot['fl']/tot['w']/1e12:.0f} TF)")
