@@ -701,7 +701,25 @@ int g_wgrad_big_min_ktiles = 20;
 int g_wgrad_big_blocks = 256;       // EESEG_OPT_WGRAD_BIG_BLOCKS: concurrent blocks the 256x256 wgrad kernel sizes its K split for
 int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this many rounds of them
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
-int g_wgrad_target_blocks = 1024;   // tiles * splits aimed at (eeseg_set_wgrad_target_blocks)
+int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_target_blocks); 0 = by the cost model below
+
+// Cost model of the 128x128-tile kernel (fitted to scripts/wgrad_sweep.py, MI355X, us): a block takes ~1.0 us per
+// 64-pixel K step alone on a CU, ~1.4 us when two share it (2 resident blocks per CU = 512 slots, more blocks queue),
+// and every block ends with one fp32 partial tile of float atomics that run at ~1.3 TB/s chip-wide WHATEVER the layer
+// size - so the block count that is best for a long K (1024) drowns a short one in atomics (50 us per call).
+struct WgPlan { long long splits; double us; };
+static WgPlan plan_wgrad128(long long M, int kp, long long tiles, double tile_bytes, long long max_splits) {
+    const double ksteps = (double)((M + kp - 1) / kp);
+    const double b = tile_bytes / 1.3e6;                       // us of atomic traffic per block
+    WgPlan best{1, 1e30};
+    for (long long sp = 1; sp <= max_splits && tiles * sp <= 1536; ++sp) {
+        const double blocks = (double)(tiles * sp);
+        const double per_step = blocks * 0.7 / 256.0 > 1.0 ? blocks * 0.7 / 256.0 : 1.0;
+        const double us = ksteps / (double)sp * per_step + b * blocks;
+        if (us < best.us * 0.98) best = WgPlan{sp, us};
+    }
+    return best;
+}
 
 }  // namespace
 
@@ -730,7 +748,7 @@ extern "C" int eeseg_set_wgrad_big(int on) {
 }
 
 extern "C" int eeseg_set_wgrad_target_blocks(int blocks) {
-    EESEG_CHECK(blocks >= 64 && blocks <= 65535, EESEG_ERR_ARG, "set_wgrad_target_blocks: out of range");
+    EESEG_CHECK(blocks == 0 || (blocks >= 64 && blocks <= 65535), EESEG_ERR_ARG, "set_wgrad_target_blocks: out of range");
     g_wgrad_target_blocks = blocks;
     return EESEG_OK;
 }
@@ -787,7 +805,18 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         p.splits = (int)splits; p.chunk = (int)chunk;
         // short K ranges (few output tiles -> many splits) leave one block per CU mostly filling and draining its
         // pipeline: measured break-even against the 128x128 kernel (2-3 blocks per CU) at ~20 K tiles per block
-        if (g_wgrad_big == 2 || chunk / 64 >= g_wgrad_big_min_ktiles) {
+        // ... and against the cost model of the 128x128 kernel: few output tiles mean many K splits, i.e. many 256-KiB
+        // partial tiles (0.2 us of atomics each) for little MFMA work per block
+        bool take_big = chunk / 64 >= g_wgrad_big_min_ktiles;
+        if (take_big && g_wgrad_target_blocks == 0) {
+            const long long t128 = (long long)((a->Cout + 127) / 128) * ((a->Cin + 127) / 128) * taps;
+            const WgPlan alt = plan_wgrad128(M, 64, t128, 65536.0, (M + 4 * 64 - 1) / (4 * 64));
+            const double blocks = (double)(tiles * splits);
+            const double rounds = (double)((tiles * splits + T - 1) / T);
+            const double big_us = rounds * (double)(chunk / 64) * 1.6 + 7.5 + 0.2 * blocks;
+            take_big = big_us <= alt.us;
+        }
+        if (g_wgrad_big == 2 || take_big) {
             // second reduce level when tiles x 8 blocks alone could not pull the slabs at the memory rate
             long long G = 512 / (tiles * 8);
             if (G > splits / 2) G = splits / 2;
@@ -816,8 +845,15 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     }
     const int kp = 128 / es;
     const long long tiles = (long long)p.co_tiles * p.ci_tiles * taps;
-    long long splits = (g_wgrad_target_blocks + tiles - 1) / tiles;
     const long long max_splits = (M + 4 * kp - 1) / (4 * kp); // at least 4 K steps per block
+    const double tile_bytes = 4.0 * (a->Cout < 128 ? a->Cout : 128) * (a->Cin < 128 ? a->Cin : 128);
+    long long splits;
+    if (g_wgrad_target_blocks > 0)
+        splits = (g_wgrad_target_blocks + tiles - 1) / tiles;
+    else if (a->dtype == EESEG_BF16 && tile_bytes >= 32768.0)
+        splits = plan_wgrad128(M, kp, tiles, tile_bytes, max_splits).splits;
+    else
+        splits = (1024 + tiles - 1) / tiles;                  // narrow (64x64) tiles and fp32: cheap atomics, many blocks
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long long chunk = (M + splits - 1) / splits;

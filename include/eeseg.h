@@ -53,7 +53,8 @@ int eeseg_set_option(int key, int value);
 int eeseg_get_option(int key);   /* current value, or a negative error code */
 /* upper bound on the grid of the column-fixed BatchNorm elementwise kernels (tuning) */
 int eeseg_set_ew_grid_cap(int blocks);
-/* split-K sizing of the weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at */
+/* split-K sizing of the 128x128-tile weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at; 0 (default) =
+ * chosen per layer by a cost model (K steps per block vs the fp32 partial tile every block adds with float atomics) */
 int eeseg_set_wgrad_target_blocks(int blocks);
 /* bf16 weight gradients with Cout % 256 == 0 and Cin % 256 == 0: 1 (default) = 256x256-tile kernel when every block
  * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel); +4 = combine the K splits through
