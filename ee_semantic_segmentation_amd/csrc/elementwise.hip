@@ -7,6 +7,8 @@
 
 int g_bn_reverse = 0;               // EESEG_OPT_BN_REVERSE: bit 0 bn_apply, bit 1 bn_bwd_apply sweep rows from the end
 
+int g_bn_rows = 2;                  // EESEG_OPT_BN_ROWS: rows of loads in flight per thread in bn_apply / bn_bwd_apply (1, 2, 4)
+
 namespace {
 
 template <typename T> struct Vec {
@@ -185,6 +187,7 @@ __device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, lo
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[k][e] = 0.f;
     if (c0 < C) {
+#pragma unroll 2
         for (long long r = row_begin + ty; r < row_end; r += TY) elem(r, c0, acc);
     }
 #pragma unroll
@@ -398,7 +401,7 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 // Column-fixed mapping: the host picks gridDim so that (gridDim.x*256) % (C/EPC) == 0, so a
 // thread owns ONE 16-byte channel chunk for its whole grid-stride loop and keeps the
 // per-channel coefficients in registers (no per-element div/mod or coefficient loads).
-template <typename TI, typename TO>
+template <typename TI, typename TO, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
                                                        int C, int relu, unsigned char* mask, int rev) {
@@ -411,43 +414,57 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
     float sc[EPC], sh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
-    for (long long r_ = gid / cpr; r_ < rows; r_ += rstep) {
-        const long long r = rev ? rows - 1 - r_ : r_;      // rev: sweep from the end (the rows the producer wrote last)
-        Vec<TI> v = ld16(x + r * ldx + c0);
-        Vec<TI> rv;
-        if (res) rv = ld16(res + r * ldres + c0);
-        float o[EPC];
+    for (long long r_ = gid / cpr; r_ < rows; r_ += U * rstep) {      // U rows of loads in flight per thread
+        long long rr[U];
+        bool on[U];
+        Vec<TI> v2[U], rv2[U];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float f = to_f32(v.e[e]) * sc[e] + sh[e];
-            if (res) f += to_f32(rv.e[e]);
-            if (relu) f = fmaxf(f, 0.f);
-            o[e] = f;
-        }
-        TO* dst = y + r * ldy + c0;
-        if constexpr (sizeof(TO) == sizeof(TI)) {
-            Vec<TO> w;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) w.e[e] = from_f32<TO>(o[e]);
-            st16(dst, w);
-            if (mask) {        // one byte per 16-byte chunk: bit e = (stored y[e] > 0), the ReLU mask of the backward
-                unsigned m = 0u;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) m |= (to_f32(w.e[e]) > 0.f ? 1u : 0u) << e;
-                mask[r * cpr + c0 / EPC] = (unsigned char)m;
+        for (int u = 0; u < U; ++u) {
+            const long long q = r_ + u * rstep;
+            on[u] = q < rows;
+            rr[u] = rev ? rows - 1 - q : q;      // rev: sweep from the end (the rows the producer wrote last)
+            if (on[u]) {
+                v2[u] = ld16(x + rr[u] * ldx + c0);
+                if (res) rv2[u] = ld16(res + rr[u] * ldres + c0);
             }
-        } else {   // bf16 in (8 elems) -> f32 out: two 16-byte stores
-            Vec<TO> w0, w1;
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { w0.e[e] = from_f32<TO>(o[e]); w1.e[e] = from_f32<TO>(o[4 + e]); }
-            st16(dst, w0);
-            st16(dst + 4, w1);
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const long long r = rr[u];
+            float o[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float f = to_f32(v2[u].e[e]) * sc[e] + sh[e];
+                if (res) f += to_f32(rv2[u].e[e]);
+                if (relu) f = fmaxf(f, 0.f);
+                o[e] = f;
+            }
+            TO* dst = y + r * ldy + c0;
+            if constexpr (sizeof(TO) == sizeof(TI)) {
+                Vec<TO> w;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) w.e[e] = from_f32<TO>(o[e]);
+                st16(dst, w);
+                if (mask) {        // one byte per 16-byte chunk: bit e = (stored y[e] > 0), the ReLU mask of the backward
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) m |= (to_f32(w.e[e]) > 0.f ? 1u : 0u) << e;
+                    mask[r * cpr + c0 / EPC] = (unsigned char)m;
+                }
+            } else {   // bf16 in (8 elems) -> f32 out: two 16-byte stores
+                Vec<TO> w0, w1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w0.e[e] = from_f32<TO>(o[e]); w1.e[e] = from_f32<TO>(o[4 + e]); }
+                st16(dst, w0);
+                st16(dst + 4, w1);
+            }
         }
     }
 }
 
 // MODE 0: train BN backward (needs x, mean/invstd, gamma, sums); MODE 1: dx = g*scale
-template <typename T, int MODE>
+template <typename T, int MODE, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy, const T* y, int ldy, const T* x,
                                                            int ldx, const float* __restrict__ mean_invstd,
                                                            const float* __restrict__ gamma,
@@ -479,28 +496,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
             ka[e] = gamma[c]; kb[e] = 0.f; kc[e] = 0.f; km[e] = 0.f;      // gamma := scale
         }
     }
-    for (long long r_ = gid / cpr; r_ < rows; r_ += rstep) {
-        const long long r = rev ? rows - 1 - r_ : r_;      // rev: against the direction of the reduction pass before
-        Vec<T> g = ld16(dy + r * lddy + c0);
-        Vec<T> yv, xv;
-        unsigned mb = 0u;
-        if (relu == 1) yv = ld16(y + r * ldy + c0);
-        if (relu == 3) mb = bmask[r * ldy + c0 / EPC];
-        if (MODE == 0) xv = ld16(x + r * ldx + c0);
-        Vec<T> od, og;
+    // U rows per iteration: all their loads are issued before any is consumed (memory-level parallelism at
+    // 2 blocks per CU)
+    for (long long r_ = gid / cpr; r_ < rows; r_ += U * rstep) {
+        long long rr[U];
+        bool on[U];
+        Vec<T> g[U], yv[U], xv[U];
+        unsigned mb[U];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            float gf = to_f32(g.e[e]);
-            if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
-            if (relu == 3 && !((mb >> e) & 1u)) gf = 0.f;
-            if (MODE == 0 && relu == 2 && !(to_f32(xv.e[e]) * msc[e] + msh[e] > 0.f)) gf = 0.f;
-            og.e[e] = from_f32<T>(gf);
-            float d = ka[e] * gf;
-            if (MODE == 0) d += kb[e] * (to_f32(xv.e[e]) - km[e]) + kc[e];
-            od.e[e] = from_f32<T>(d);
+        for (int u = 0; u < U; ++u) {
+            mb[u] = 0u;
+            const long long q = r_ + u * rstep;
+            on[u] = q < rows;
+            rr[u] = rev ? rows - 1 - q : q;      // rev: against the direction of the reduction pass before
+            if (on[u]) {
+                g[u] = ld16(dy + rr[u] * lddy + c0);
+                if (relu == 1) yv[u] = ld16(y + rr[u] * ldy + c0);
+                if (relu == 3) mb[u] = bmask[rr[u] * ldy + c0 / EPC];
+                if (MODE == 0) xv[u] = ld16(x + rr[u] * ldx + c0);
+            }
         }
-        st16(dx + r * lddx + c0, od);
-        if (dres) st16(dres + r * lddres + c0, og);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const long long r = rr[u];
+            Vec<T> od, og;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float gf = to_f32(g[u].e[e]);
+                if (relu == 1 && !(to_f32(yv[u].e[e]) > 0.f)) gf = 0.f;
+                if (relu == 3 && !((mb[u] >> e) & 1u)) gf = 0.f;
+                if (MODE == 0 && relu == 2 && !(to_f32(xv[u].e[e]) * msc[e] + msh[e] > 0.f)) gf = 0.f;
+                og.e[e] = from_f32<T>(gf);
+                float d = ka[e] * gf;
+                if (MODE == 0) d += kb[e] * (to_f32(xv[u].e[e]) - km[e]) + kc[e];
+                od.e[e] = from_f32<T>(d);
+            }
+            st16(dx + r * lddx + c0, od);
+            if (dres) st16(dres + r * lddres + c0, og);
+        }
     }
 }
 
@@ -798,8 +832,9 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(T* y, const T* x, long
 }
 
 // grid for the column-fixed kernels: total threads must be a multiple of chunks-per-row
-int g_colfixed_cap = 1024;          // eeseg_set_ew_grid_cap(): 4 blocks/CU; each thread then amortises its
-                                    // per-channel coefficient prologue over >= 8 rows (+6% end to end vs 4096)
+int g_colfixed_cap = 512;           // eeseg_set_ew_grid_cap(): 2 blocks/CU; each thread then amortises its per-channel
+                                    // coefficient prologue over many rows (end to end: 4096 -> 1024 +6 %, 1024 -> 512 +1.3 % at
+                                    // B=16 and +4 % at B=4; the row loops keep two rows of loads in flight per thread)
 inline int colfixed_grid(long long rows, int cpr) {
     long long items = rows * cpr;
     long long b = (items + 255) / 256;
@@ -1017,13 +1052,25 @@ static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const
     const int g = colfixed_grid(rows, C / epc);
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
-        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
                            scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
-        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
                            scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
-        hipLaunchKernelGGL((bn_apply_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<float, float, 4>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<float, float, 2>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+        else hipLaunchKernelGGL((bn_apply_kernel<float, float, 1>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
                            scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
     } else {
         EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
@@ -1140,14 +1187,28 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     const int epc = 16 / eeseg_dtype_size(dtype);
     const int g = colfixed_grid(rows, C / epc);
     const float inv = (float)(1.0 / count);
-    if (dtype == EESEG_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+    if (dtype == EESEG_BF16) {
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
                            lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+    }
+    else {
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
                            (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+    }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
@@ -1163,16 +1224,34 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
     hipStream_t st = (hipStream_t)stream;
     const int epc = 16 / eeseg_dtype_size(dtype);
     const int g = colfixed_grid(rows, C / epc);
-    if (dtype == EESEG_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+    if (dtype == EESEG_BF16) {
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr, 0);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr, 0);
+    }
+    else {
+        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);
+        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr, 0);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+                           (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
+                           (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
+                           (const float*)nullptr, 0);
+    }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
