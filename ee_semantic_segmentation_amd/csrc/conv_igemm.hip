@@ -1100,6 +1100,7 @@ int launch(const ConvP& p, hipStream_t st) {
 extern int g_ce_span;     // loss.hip
 extern int g_bn_reverse;  // elementwise.hip
 extern int g_bn_rows;
+extern int g_colreduce_blocks;
 
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
@@ -1112,6 +1113,10 @@ extern "C" int eeseg_set_option(int key, int value) {
     }
     if (key == EESEG_OPT_CONV_NARROW_MAX && value >= 64 && value <= 4096) {
         g_conv_narrow_max = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_COLREDUCE_BLOCKS && value >= 0 && value <= 65536) {
+        g_colreduce_blocks = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_BN_ROWS && (value == 1 || value == 2 || value == 4)) {
@@ -1158,6 +1163,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_CUS: return g_conv_big_cus;
         case EESEG_OPT_BN_REVERSE: return g_bn_reverse;
         case EESEG_OPT_BN_ROWS: return g_bn_rows;
+        case EESEG_OPT_COLREDUCE_BLOCKS: return g_colreduce_blocks;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
