@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     }
 }
 
+int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K range of a split tail tile holds at least
 int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
@@ -1043,7 +1044,7 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     int ksplit = 1;
     if (rem > 0 && rem < g_conv_big_tail_min * cus / 256) {
         ksplit = cus / rem;
-        if (ksplit > nk_max / 4) ksplit = nk_max / 4;            // at least 4 K tiles per range (pipeline fill)
+        if (ksplit > nk_max / g_conv_big_split_min_k) ksplit = nk_max / g_conv_big_split_min_k;   // at least 4 K tiles per range (pipeline fill)
         const long long fit = workspace ? workspace_bytes / ((long long)rem * SLAB_FLOATS * 4) : 0;
         if (ksplit > fit) ksplit = (int)fit;
     }
@@ -1115,6 +1116,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_narrow_max = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_SPLIT_MIN_K && value >= 1 && value <= 64) {
+        g_conv_big_split_min_k = value;
+        return EESEG_OK;
+    }
     if (key == EESEG_OPT_COLREDUCE_BLOCKS && value >= 0 && value <= 65536) {
         g_colreduce_blocks = value;
         return EESEG_OK;
@@ -1164,6 +1169,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_BN_REVERSE: return g_bn_reverse;
         case EESEG_OPT_BN_ROWS: return g_bn_rows;
         case EESEG_OPT_COLREDUCE_BLOCKS: return g_colreduce_blocks;
+        case EESEG_OPT_CONV_SPLIT_MIN_K: return g_conv_big_split_min_k;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
