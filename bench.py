@@ -105,8 +105,9 @@ def main():
     ap.add_argument("--wgrad-blocks", type=int, default=None)
     ap.add_argument("--conv-narrow-max", type=int, default=None)
     ap.add_argument("--conv-auto-narrow", type=int, default=None)
-    ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="run weight-gradient kernels on a side stream (+1%%; per-kernel timings then overlap)")
+    ap.add_argument("--overlap-wgrad", type=int, default=0, nargs="?", const=1,
+                    help="weight-gradient kernels on a side stream: 1 = beside the data-gradient, 2 = after it, beside the "
+                         "BatchNorm backward of the layer below (per-kernel timings then overlap)")
     args = ap.parse_args()
 
     # RCCL / HIP print banners on stdout: keep fd 1 for the single JSON line only
@@ -206,7 +207,7 @@ def main():
     prof = None
     prof_steps = 0
     if not args.no_kernel_events and rank == 0 or (not args.no_kernel_events and world > 1):
-        net.cfg.overlap_wgrad = False          # per-kernel events need a serial timeline
+        net.cfg.overlap_wgrad = 0              # per-kernel events need a serial timeline
         K.PROFILE = []
         for _ in range(args.roofline_steps):
             runner._eager(X, y)

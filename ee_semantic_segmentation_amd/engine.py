@@ -84,6 +84,8 @@ class Config:
         return None if self.arena is None else self.arena.kernel_view.get(param)
 
     def unit_done(self, module):
+        if self.overlap_wgrad == 2 and self.on_unit_done is None:
+            return                           # nobody consumes the gradients before the optimizer step: join there
         self.join_side()                     # the unit's weight gradients are complete from here on
         if self.on_unit_done is not None:
             uid = module.__dict__.get("_eeseg_unit")
@@ -321,7 +323,20 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         return K.conv_wgrad(x, dc, R, S, s, p, d).permute(0, 3, 1, 2)
 
     dx = None
-    if need_dx and cfg.overlap_wgrad and dc.is_cuda:
+    if need_dx and cfg.overlap_wgrad == 2 and dc.is_cuda:
+        # data-gradient first on the main stream, THEN the weight-gradient on the side stream: it runs beside the
+        # BatchNorm-backward passes of the layer below (HBM-bound, few registers, small LDS: their blocks fit on a CU next
+        # to a one-block-per-CU MFMA kernel) instead of competing with the data-gradient for the CUs
+        _, wb = packed(conv, dc.dtype)
+        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+        cur = torch.cuda.current_stream(dc.device)
+        side = cfg.side_stream(dc.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            dwp = wgrad()
+        cfg._side_busy = True
+        cfg._side_keep.append((x, dc, dwp))
+    elif need_dx and cfg.overlap_wgrad and dc.is_cuda:
         # fork: wgrad goes to the side stream and runs concurrently with the data-gradient and the
         # following BatchNorm-backward kernels of this unit; Config.unit_done() joins.  The tensors it
         # reads are kept alive until then so the allocator cannot hand their memory out early.
