@@ -932,7 +932,27 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ws = p.slabs + (size_t)tile_local * p.ksplit * SLAB_FLOATS + ((wp * 4 + wc) * 32 + j * 4) * 256 + lane * 4;
-    for (int s = 0; s < p.ksplit; ++s) {
+    // four K ranges per iteration: 32 independent 16-byte loads in flight per lane (one range at a time made this kernel a
+    // chain of ksplit load latencies); the additions keep the order of the ranges
+    int s = 0;
+    for (; s + 4 <= p.ksplit; s += 4) {
+        f32x4 t[4][2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    t[u][i][g] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * SLAB_FLOATS + (i * 16 + g) * 256);
+        __builtin_amdgcn_sched_barrier(0);     // all 32 loads issued before the first add (else the scheduler trades them for registers)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[i][g] += t[u][i][g];
+    }
+    for (; s < p.ksplit; ++s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

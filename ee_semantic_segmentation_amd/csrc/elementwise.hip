@@ -329,7 +329,19 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         float a0 = 0.f, b0 = 0.f;
-        for (int t = tl; t < tiles; t += 64) {
+        int t = tl;
+        for (; t + 192 < tiles; t += 256) {              // 8 loads in flight; the additions keep the tile order
+            float u[4], v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u[k] = partials[((long long)(t + 64 * k) * 2 + 0) * C + c];
+                v[k] = partials[((long long)(t + 64 * k) * 2 + 1) * C + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0 += u[k]; b0 += v[k]; }
+        }
+        for (; t < tiles; t += 64) {
             a0 += partials[((long long)t * 2 + 0) * C + c];
             b0 += partials[((long long)t * 2 + 1) * C + c];
         }
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
                 if (res) rv2[u] = ld16(res + rr[u] * ldres + c0);
             }
         }
+        if (U > 1) __builtin_amdgcn_sched_barrier(0);      // every row's loads issued before the first is consumed
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
@@ -518,6 +531,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
                 if (MODE == 0) xv[u] = ld16(x + rr[u] * ldx + c0);
             }
         }
+        if (U > 1) __builtin_amdgcn_sched_barrier(0);      // every row's loads issued before the first is consumed
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
