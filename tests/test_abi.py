@@ -71,3 +71,26 @@ def test_no_cpu_fallback():
     with pytest.raises(_lib.EesegError):
         kernels.maxpool3x3s2.__wrapped__ if hasattr(kernels.maxpool3x3s2, "__wrapped__") else None
         kernels.conv_fwd(torch.zeros(1, 4, 4, 64), torch.zeros(64, 1, 1, 64))
+
+
+def test_option_table_round_trips(built_lib):
+    """Every EESEG_OPT_* key of the header: the documented default comes back from eeseg_get_option, a legal value
+    round-trips, an illegal one is refused with EESEG_ERR_ARG and leaves the setting alone.  Host-side state only."""
+    from ee_semantic_segmentation_amd import _lib
+    l = _lib.lib()
+    txt = open(HEADER).read()
+    keys = {m.group(1): int(m.group(2)) for m in re.finditer(r"(EESEG_OPT_\w+)\s*=\s*(\d+)", txt)}
+    assert len(keys) >= 12 and len(set(keys.values())) == len(keys)
+    # key: (default, another legal value, an illegal value)
+    table = {"EESEG_OPT_CONV_PIPE": (3, 0, 9), "EESEG_OPT_CONV_TAP_INNER": (0, 1, 2), "EESEG_OPT_CONV_NARROW_MAX": (64, 128, 1),
+             "EESEG_OPT_CONV_AUTO_NARROW": (0, 1, 2), "EESEG_OPT_CONV_TAIL_MIN": (224, 0, 999), "EESEG_OPT_CE_SPAN": (1, 0, 2),
+             "EESEG_OPT_CONV_TAIL_MERGE": (1, 0, 2), "EESEG_OPT_CONV_CUS": (256, 240, 8), "EESEG_OPT_BN_REVERSE": (0, 3, 4),
+             "EESEG_OPT_BN_ROWS": (2, 4, 3), "EESEG_OPT_COLREDUCE_BLOCKS": (512, 0, -1), "EESEG_OPT_CONV_SPLIT_MIN_K": (4, 8, 0)}
+    assert set(table) == set(keys), set(table) ^ set(keys)
+    for name, (default, other, bad) in table.items():
+        k = keys[name]
+        assert l.eeseg_get_option(k) == default, name
+        assert l.eeseg_set_option(k, other) == 0 and l.eeseg_get_option(k) == other, name
+        assert l.eeseg_set_option(k, bad) != 0 and l.eeseg_get_option(k) == other, name
+        assert l.eeseg_set_option(k, default) == 0
+    assert l.eeseg_set_option(999, 0) != 0 and l.eeseg_get_option(999) < 0
