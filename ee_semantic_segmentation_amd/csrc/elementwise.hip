@@ -162,6 +162,54 @@ __global__ void im2col_nchw_kernel(const float* __restrict__ x, T* col, int N, i
     }
 }
 
+// The same through LDS: one block = IM2COL_TPX consecutive output pixels of one output row.  The C x R x span input
+// patch they see is loaded once, coalesced along w (the thread-per-output-chunk form issues one 4-byte load per lane and
+// k, every lane on a line of its own), then each thread assembles 16-byte output chunks from LDS.
+constexpr int IM2COL_TPX = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __restrict__ x, T* col, int N, int C, int H,
+                                                               int W, int R, int S, int stride, int pad, int Ho, int Wo,
+                                                               int Kpad, int wo_tiles) {
+    extern __shared__ float patch[];                          // [C][R][span]
+    const int span = (IM2COL_TPX - 1) * stride + S;
+    int b = blockIdx.x;
+    const int wt = b % wo_tiles; b /= wo_tiles;
+    const int ho = b % Ho;
+    const int n = b / Ho;
+    const int wo0 = wt * IM2COL_TPX;
+    const int hb = ho * stride - pad, wb = wo0 * stride - pad;
+    const float* xn = x + (long long)n * C * H * W;
+    const int rows = C * R;
+    for (int i = threadIdx.x; i < rows * span; i += 256) {
+        const int row = i / span, j = i - row * span;
+        const int ci = row / R, r = row - ci * R;
+        const int hi = hb + r, wi = wb + j;
+        float v = 0.f;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = xn[((long long)ci * H + hi) * W + wi];
+        patch[i] = v;
+    }
+    __syncthreads();
+    const int KG = Kpad / 8, K = R * S * C;
+    const int npx = min(IM2COL_TPX, Wo - wo0);
+    for (int i = threadIdx.x; i < npx * KG; i += 256) {
+        const int px = i / KG, kg = i - px * KG;
+        const int k0 = kg * 8;
+        int tap = k0 / C, ci = k0 - tap * C;
+        int r = tap / S, sx = tap - r * S;
+        union { T e[8]; i32x4 q4[sizeof(T) == 2 ? 1 : 2]; } out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (k0 + e < K) ? patch[(ci * R + r) * span + px * stride + sx] : 0.f;
+            out.e[e] = from_f32<T>(v);
+            if (++ci == C) { ci = 0; if (++sx == S) { sx = 0; ++r; } }
+        }
+        const long long m = ((long long)n * Ho + ho) * Wo + wo0 + px;
+        i32x4* dst = reinterpret_cast<i32x4*>(col + m * Kpad + k0);
+        dst[0] = out.q4[0];
+        if constexpr (sizeof(T) == 4) dst[1] = out.q4[1];
+    }
+}
+
 // =========================================================================
 // column reductions: [rows][C] -> K sums per channel, two deterministic stages
 // block = (32 chunk-columns, 8 row lanes); grid = (col blocks, row blocks, batch)
@@ -965,6 +1013,19 @@ extern "C" int eeseg_im2col_nchw(const float* x, void* col, int N, int C, int H,
                 "im2col: inconsistent output size");
     const long long total = (long long)N * Ho * Wo * (Kpad / 8);
     hipStream_t st = (hipStream_t)stream;
+    const long long lds = (long long)C * R * ((IM2COL_TPX - 1) * stride + S) * (long long)sizeof(float);
+    const int wo_tiles = (Wo + IM2COL_TPX - 1) / IM2COL_TPX;
+    const long long blocks = (long long)N * Ho * wo_tiles;
+    if (lds <= 48 * 1024 && blocks < (1ll << 31)) {        // the stem: 3 x 7 x 133 floats = 11 KiB
+        if (dtype == EESEG_BF16)
+            hipLaunchKernelGGL((im2col_nchw_tile_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x,
+                               (bf16_t*)col, N, C, H, W, R, S, stride, pad, Ho, Wo, Kpad, wo_tiles);
+        else
+            hipLaunchKernelGGL((im2col_nchw_tile_kernel<float>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x,
+                               (float*)col, N, C, H, W, R, S, stride, pad, Ho, Wo, Kpad, wo_tiles);
+        EESEG_LAUNCH_CHECK();
+        return EESEG_OK;
+    }
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((im2col_nchw_kernel<bf16_t>), dim3(ew_grid(total)), dim3(256), 0, st, x, (bf16_t*)col, N, C,
                            H, W, R, S, stride, pad, Ho, Wo, Kpad);

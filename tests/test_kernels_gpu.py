@@ -132,6 +132,25 @@ def test_stem_im2col_gemm(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 41, 300, 7, 2, 3), (1, 3, 9, 131, 7, 2, 3), (2, 4, 20, 70, 3, 1, 1)],
+                         ids=["three_wo_tiles", "ragged", "3x3_s1"])
+def test_im2col_matches_unfold(shape, dtype):
+    """The LDS-tiled im2col (64 output pixels of one row per block) against torch's unfold, bit exact: several pixel
+    tiles per row, a ragged last tile, borders on all four sides; K order (tap, ci), zero padding up to Kpad."""
+    N, Cc, H, W, k, stride, pad = shape
+    x = torch.randn(N, Cc, H, W, generator=torch.Generator().manual_seed(3))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    Kd = k * k * Cc
+    Kpad = (Kd + 63) // 64 * 64
+    col = K.im2col_nchw(x.to(DEV), k, k, stride, pad, Kpad, dtype)
+    want = F.unfold(x, k, padding=pad, stride=stride)                    # [N, C*k*k, L], row index (ci, r, s)
+    want = want.view(N, Cc, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, Kd).to(dtype)
+    got = col.reshape(N * Ho * Wo, Kpad).cpu()
+    assert torch.equal(got[:, :Kd], want)
+    assert torch.count_nonzero(got[:, Kd:]) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
 def test_batchnorm_train_fwd_bwd(dtype, relu, use_res):
     N, H, W, Cc = 3, 23, 19, 128
