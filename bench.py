@@ -182,7 +182,10 @@ def main():
         return runner(X, y)
 
     log(f"model ready: {args.arch} E={E} {img}x{img} B={B}/GPU {args.dtype}; warmup {args.warmup}")
-    for i in range(max(args.warmup, 0 if args.no_graph else 4)):
+    # the graph path needs 4 untimed steps (2 eager, the capture, a first replay): --warmup below that is raised, and the
+    # number actually run is reported as config.warmup_steps_run
+    warmup_run = max(args.warmup, 0 if args.no_graph else 4)
+    for i in range(warmup_run):
         l = step()
         if rank == 0:
             torch.cuda.synchronize()
@@ -255,7 +258,7 @@ def main():
                 "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
                                        f"per-exit CE (sum), SGD momentum 0.9 wd 5e-4",
                            "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
-                           "hip_graph": bool(runner.graph is not None),
+                           "hip_graph": bool(runner.graph is not None), "warmup_steps_run": warmup_run,
                            "flop_per_image": flop_img, "loss_last_step": loss_val},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
