@@ -34,6 +34,19 @@ def test_main_entry_point_trains_and_tests(tmp_path, monkeypatch, loss):
     assert os.path.samefile(out, tmp_path / "voc_seg_results" / "t50" / "t50.pth")
 
 
+def test_main_bradeepv3_ce_at_the_baseline_plumbing_shape(tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: main_bradeepv3_ce, DeepLabV3-ResNet50, 2 exits, 256x256, B=2, 21 classes (the reference's
+    CPU-runnable plumbing case), through the reference's own flags; fp32 = the parity mode."""
+    from ee_semantic_segmentation_amd import main_bradeepv3
+    monkeypatch.chdir(tmp_path)
+    out = main_bradeepv3.main("ce", ["-t", "resnet50", "-n", "1", "-e", "2", "-N", "c1", "--dim", "256", "--batch", "2"])
+    sd = torch.load(out, weights_only=True)
+    assert sd["branches.0.4.weight"].shape[0] == 21 and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
+    rows = open(tmp_path / "mIoU_1_branches_results.csv").read().strip().splitlines()
+    vals = [float(v) for v in rows[1].split(",")[1:]]
+    assert len(vals) == 2 and all(0.0 <= v <= 1.0 or v != v for v in vals)      # NaN allowed: reference quirk B-8
+
+
 def test_br_evaluator_and_progressive_inference():
     from ee_semantic_segmentation_amd.eval_br_ent import br_evaluator, img_norm_entropy
     from ee_semantic_segmentation_amd.ee_dnn_op_ne import eval_ee_deeplabv3
