@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--classes", type=int, default=21)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--loss", default="ce", choices=["ce", "lovasz"],
+                    help="ce = BrXEntropyLoss (the headline workload); lovasz = BSL.LovaszSoftmax (BASELINE configs[4] shape)")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="N>1: CUs the conv launch plans leave to RCCL while gradient buckets are in flight (default: "
@@ -165,7 +167,11 @@ def main():
     net.cfg.overlap_wgrad = args.overlap_wgrad
     broadcast_parameters(net)
     E = net.n_branches + 1
-    crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)
+    if args.loss == "lovasz":
+        from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
+        crit = BSL.LovaszSoftmax(ignore=C, n_branches=E - 1)
+    else:
+        crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)
     lr = 0.01                                                  # param groups as deepv3_funcs.py:74-99
     opt = SGD([{"params": net.base_model.parameters(), "lr": lr},
                {"params": net.branches.parameters(), "lr": lr},
@@ -256,7 +262,7 @@ def main():
                 "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
-                                       f"per-exit CE (sum), SGD momentum 0.9 wd 5e-4",
+                                       f"{'per-exit CE (sum)' if args.loss == 'ce' else 'raw-logit Lovasz (sum over exits)'}, SGD momentum 0.9 wd 5e-4",
                            "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
                            "hip_graph": bool(runner.graph is not None), "warmup_steps_run": warmup_run,
                            "flop_per_image": flop_img, "loss_last_step": loss_val},
