@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of one data-parallel training step (forward +
-backward + SGD step) of the early-exit DeepLabV3 on synthetic 513x513 batches.
+backward + gradient all-reduce + SGD step) of the early-exit DeepLabV3 on synthetic
+513x513 batches.
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload at N=1 = BASELINE.json configs[1]: DeepLabV3-ResNet50, 2 exits, 513x513,
-B=16, 21 classes, bf16 MFMA compute (fp32 master weights / statistics / loss).
-N>1 keeps 16 images per GPU (weak scaling); gradients are all-reduced over RCCL.
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`
-(live HIP-event timing of the dominant conv kernel family vs the dense bf16 MFMA
-peak) and, at N=1, `cpu_baseline` (the oracle = torch CPU fp32 restatement of the
-reference path, timed on a bounded sample on this host's cores).
+Workload = the configuration BASELINE.json's metric is quoted on ("images/sec at
+513x513 B=32 fwd+bwd, 1/2/4/8 MI355X" = configs[2]): DeepLabV3-ResNet101, 3 exits,
+19 classes, 513x513, GLOBAL batch 32 (the reference trains at batch 32,
+main_bradeepv3.py:119) -> 32/N images per GPU ("scaling": "strong"), bf16 MFMA compute
+with fp32 master weights / statistics / loss, SyncBN over the N ranks (so BatchNorm sees
+the reference's batch-32 statistics), gradients all-reduced over RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) with
+  * `roofline`: live HIP-event timing of the dominant conv kernel family vs the dense bf16
+    MFMA peak, plus the 3x3-stack aggregate the north-star target names;
+  * `cpu_baseline` (N=1): the oracle (torch CPU fp32 restatement of the reference path) timed
+    on a bounded sample of the same architecture on this host's cores;
+  * `secondary` (N=1): BASELINE configs[1] (R50, 2 exits, 21 classes, B=16, bf16) and the fp32
+    parity mode of the headline workload (the mode the 1e-3 logit bar is held in).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -26,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3        # v_mfma_f32_32x32x2_f32
 PEAK_HBM_GBS = 8000.0
 
 
@@ -61,18 +70,139 @@ def cpu_baseline(arch, n_branches, C, img, B, seed):
 
     xs, ts = synth_batch(2, C, 65, 65, seed, "cpu")
     step(xs, ts)                                   # page in kernels / allocator
-    n = 4                                          # ~10 s of CPU work on the GPU box's 16-core share
+    n = 3                                          # ~15-25 s of CPU work on the GPU box's 16-core share
     t0 = time.perf_counter()
     for _ in range(n):
         step(X, y)
     dt = time.perf_counter() - t0
     return {"value": n * B / dt, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} timed fwd+bwd+SGD steps of the torch-CPU fp32 oracle, {arch} {n_branches + 1} exits, "
-                      f"{img}x{img}, B={B} ({dt:.1f} s)"}
+                      f"{C} classes, {img}x{img}, B={B} ({dt:.1f} s)"}
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+class Run:
+    """One workload: network + loss + optimizer + (graphed) step on this rank's shard."""
+
+    def __init__(self, arch, branches, classes, img, batch, dtype, loss, sync_bn, world, rank, dev, args):
+        from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
+        from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+        from ee_semantic_segmentation_amd.optim import SGD
+        from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, broadcast_parameters
+        self.arch, self.C, self.img, self.B, self.dtype, self.loss_name = arch, classes, img, batch, dtype, loss
+        self.world = world
+        torch.manual_seed(0)
+        net = branchyDeepv3(None, f"deeplabv3_{arch}", branches, img, count_branches=False, num_classes=classes,
+                            compute_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32,
+                            fused_outputs=True).to(dev)
+        net.cfg.sync_bn = bool(sync_bn and world > 1)
+        net.cfg.overlap_wgrad = args.overlap_wgrad
+        broadcast_parameters(net)
+        self.E = net.n_branches + 1
+        if loss == "lovasz":
+            from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
+            crit = BSL.LovaszSoftmax(ignore=classes, n_branches=self.E - 1)
+        else:
+            crit = BrXEntropyLoss(ignore_index=classes, b_reduction="sum", n_exits=self.E)
+        lr = 0.01                                                  # param groups as deepv3_funcs.py:74-99
+        opt = SGD([{"params": net.base_model.parameters(), "lr": lr},
+                   {"params": net.branches.parameters(), "lr": lr},
+                   {"params": net.classifier.parameters(), "lr": lr * 1.1}], lr=lr, momentum=0.9, weight_decay=5e-4)
+        net.enable_grad_arena()
+        reducer = ArenaReducer(net, reserve_cus=args.reserve_cus)
+        self.X, self.y = synth_batch(batch, classes, img, img, 1234 + rank, dev)
+        net.train()
+        # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
+        # HIP graph and every later call is a replay
+        self.runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2, use_graph=not args.no_graph)
+        self.net = net
+
+    def step(self):
+        return self.runner(self.X, self.y)
+
+    def workload(self):
+        loss = "per-exit CE (sum)" if self.loss_name == "ce" else "raw-logit Lovasz (sum over exits)"
+        return (f"DeepLabV3-{self.arch} {self.E} exits, {self.img}x{self.img}, {self.C} classes, global B="
+                f"{self.world * self.B} ({self.B}/GPU), {loss}, SGD momentum 0.9 wd 5e-4, {self.dtype}")
+
+    def flop_per_image(self):
+        return 3 * 2.0 * self.net.macs(self.img)                  # fwd + bwd = 3 x fwd, FLOP = 2 MAC
+
+
+def timed(run, steps, warmup, world, rank, no_graph):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize fences."""
+    # the graph path needs 4 untimed steps (2 eager, the capture, a first replay): --warmup below that is raised, and
+    # the number actually run is reported as config.warmup_steps_run
+    warmup_run = max(warmup, 0 if no_graph else 4)
+    for i in range(warmup_run):
+        l = run.step()
+        if rank == 0:
+            torch.cuda.synchronize()
+            log(f"warmup {i} done, loss {float(l.item()):.4f}")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = run.step()
+    fence()
+    dt = time.perf_counter() - t0
+    return dt, float(last.item()), warmup_run
+
+
+def kernel_events(run, nsteps):
+    """Per-kernel HIP-event timing: graph replays cannot be bracketed kernel by kernel, so the same
+    step runs eagerly (identical kernels / shapes / launch plans) right after the timed region."""
+    from ee_semantic_segmentation_amd import kernels as K
+    run.net.cfg.overlap_wgrad = 0              # per-kernel events need a serial timeline
+    K.PROFILE = []
+    for _ in range(nsteps):
+        run.runner._eager(run.X, run.y)
+    torch.cuda.synchronize()
+    prof, K.PROFILE = K.PROFILE, None
+    return prof
+
+
+def roofline(prof, prof_steps, dtype, workload_key):
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    fam, k3 = {}, [0.0, 0.0, 0]
+    for name, flops, e0, e1, nbytes, tag in prof:
+        sec = e0.elapsed_time(e1) * 1e-3
+        f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+        f[0] += flops
+        f[1] += sec
+        f[2] += 1
+        f[3] += nbytes
+        if tag.startswith("3x3"):
+            k3[0] += flops
+            k3[1] += sec
+            k3[2] += 1
+    name, (fl, sec, cnt, nb) = max(fam.items(), key=lambda kv: kv[1][1])
+    traffic, tsrc = None, None          # HBM bytes per launch from rocprofv3 PMC passes (profiles/, offline)
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        t = json.load(open(tpath))
+        if t.get("workload_key") == workload_key:
+            traffic = t.get("hbm_bytes_per_launch", {}).get(name)
+            tsrc = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes of this workload; not collected in this run)"
+    return {"kernel": name, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": fl / sec / 1e12 / peak, "traffic": traffic, "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": nb / cnt, "flops_per_launch": fl / cnt,
+            "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
+            "measured": f"HIP events around every launch, {prof_steps} eager steps after the timed region",
+            "stack_3x3": {"what": "all 3x3 / atrous conv calls (forward, data-gradient, weight-gradient), every kernel family",
+                          "tflops": k3[0] / max(k3[1], 1e-12) / 1e12, "frac": k3[0] / max(k3[1], 1e-12) / 1e12 / peak,
+                          "ms_per_step": k3[1] / prof_steps * 1e3, "launches_per_step": k3[2] / prof_steps},
+            "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / prof_steps * 1e3,
+                             "launches_per_step": v[2] / prof_steps} for k, v in fam.items()}}
 
 
 def main():
@@ -80,33 +210,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--branches", type=int, default=1)
+    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--branches", type=int, default=2)
     ap.add_argument("--img", type=int, default=513)
-    ap.add_argument("--batch-per-gpu", type=int, default=16)
-    ap.add_argument("--classes", type=int, default=21)
+    ap.add_argument("--global-batch", type=int, default=32, help="images per step over ALL ranks (strong scaling)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="override: fixed images per GPU (weak scaling; other BASELINE shapes)")
+    ap.add_argument("--classes", type=int, default=19)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--loss", default="ce", choices=["ce", "lovasz"],
                     help="ce = BrXEntropyLoss (the headline workload); lovasz = BSL.LovaszSoftmax (BASELINE configs[4] shape)")
-    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true", help="N>1: local-batch BatchNorm instead of SyncBN")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="N>1: CUs the conv launch plans leave to RCCL while gradient buckets are in flight (default: "
                          "EESEG_RCCL_RESERVE_CUS or 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no HIP-graph replay)")
     ap.add_argument("--roofline-steps", type=int, default=2)
-    ap.add_argument("--conv-tap-inner", type=int, default=None, help="override EESEG_OPT_CONV_TAP_INNER (0|1)")
     ap.add_argument("--wgrad-big-grid", type=str, default=None, metavar="BLOCKS,ROUNDS",
                     help="eeseg_set_wgrad_big_grid: concurrent blocks / max rounds of the 256x256 wgrad kernel")
     ap.add_argument("--wgrad-big-min-ktiles", type=int, default=None)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="A/B switch: eeseg_set_option(KEY, VALUE) (include/eeseg.h EESEG_OPT_*); repeatable")
-    ap.add_argument("--conv-pipe", type=int, default=None, help="override EESEG_OPT_CONV_PIPE (1|2)")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
-    ap.add_argument("--conv-narrow-max", type=int, default=None)
-    ap.add_argument("--conv-auto-narrow", type=int, default=None)
     ap.add_argument("--overlap-wgrad", type=int, default=0, nargs="?", const=1,
                     help="weight-gradient kernels on a side stream: 1 = beside the data-gradient, 2 = after it, beside the "
                          "BatchNorm backward of the layer below (per-kernel timings then overlap)")
@@ -129,15 +258,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
-    from ee_semantic_segmentation_amd import kernels as K
-    from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
-    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
-    from ee_semantic_segmentation_amd.optim import SGD
-    from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, broadcast_parameters
-
     from ee_semantic_segmentation_amd._lib import lib as _eelib
-    if args.conv_tap_inner is not None:
-        _eelib().eeseg_set_option(2, args.conv_tap_inner)
     if args.wgrad_big_min_ktiles is not None:
         _eelib().eeseg_set_wgrad_big_min_ktiles(args.wgrad_big_min_ktiles)
     if args.wgrad_big_grid:
@@ -148,128 +269,86 @@ def main():
         k, v = kv.split("=")
         if _eelib().eeseg_set_option(int(k), int(v)) != 0:
             raise SystemExit(f"bad --opt {kv}")
-    if args.conv_pipe is not None:
-        _eelib().eeseg_set_option(1, args.conv_pipe)
     if args.ew_grid_cap is not None:
         _eelib().eeseg_set_ew_grid_cap(args.ew_grid_cap)
-    if args.conv_auto_narrow is not None:
-        _eelib().eeseg_set_option(4, args.conv_auto_narrow)
-    if args.conv_narrow_max is not None:
-        _eelib().eeseg_set_option(3, args.conv_narrow_max)
     if args.wgrad_blocks is not None:
         _eelib().eeseg_set_wgrad_target_blocks(args.wgrad_blocks)
-    C, img, B = args.classes, args.img, args.batch_per_gpu
-    torch.manual_seed(0)
-    net = branchyDeepv3(None, f"deeplabv3_{args.arch}", args.branches, img, count_branches=False, num_classes=C,
-                        compute_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32,
-                        fused_outputs=True).to(dev)
-    net.cfg.sync_bn = args.sync_bn and world > 1
-    net.cfg.overlap_wgrad = args.overlap_wgrad
-    broadcast_parameters(net)
-    E = net.n_branches + 1
-    if args.loss == "lovasz":
-        from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
-        crit = BSL.LovaszSoftmax(ignore=C, n_branches=E - 1)
+
+    if args.batch_per_gpu is not None:
+        B, scaling = args.batch_per_gpu, "weak"
     else:
-        crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=E)
-    lr = 0.01                                                  # param groups as deepv3_funcs.py:74-99
-    opt = SGD([{"params": net.base_model.parameters(), "lr": lr},
-               {"params": net.branches.parameters(), "lr": lr},
-               {"params": net.classifier.parameters(), "lr": lr * 1.1}], lr=lr, momentum=0.9, weight_decay=5e-4)
-    net.enable_grad_arena()
-    reducer = ArenaReducer(net, reserve_cus=args.reserve_cus)
-    X, y = synth_batch(B, C, img, img, 1234 + rank, dev)
-    net.train()
-    # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
-    # HIP graph and every later call is a replay
-    runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2, use_graph=not args.no_graph)
-
-    def step():
-        return runner(X, y)
-
-    log(f"model ready: {args.arch} E={E} {img}x{img} B={B}/GPU {args.dtype}; warmup {args.warmup}")
-    # the graph path needs 4 untimed steps (2 eager, the capture, a first replay): --warmup below that is raised, and the
-    # number actually run is reported as config.warmup_steps_run
-    warmup_run = max(args.warmup, 0 if args.no_graph else 4)
-    for i in range(warmup_run):
-        l = step()
-        if rank == 0:
-            torch.cuda.synchronize()
-            log(f"warmup {i} done, loss {float(l.item()):.4f}")
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    fence()
-    dt = time.perf_counter() - t0
+        if args.global_batch % world:
+            raise SystemExit(f"global batch {args.global_batch} is not divisible by {world} ranks")
+        B, scaling = args.global_batch // world, "strong"
+    run = Run(args.arch, args.branches, args.classes, args.img, B, args.dtype, args.loss, not args.no_sync_bn, world,
+              rank, dev, args)
+    log(f"model ready: {run.workload()}; warmup {args.warmup}")
+    dt, loss_val, warmup_run = timed(run, args.steps, args.warmup, world, rank, args.no_graph)
     log(f"timed {args.steps} steps in {dt:.3f} s")
-    loss_val = float(last.item())
-    # per-kernel HIP-event timing for the roofline: graph replays cannot be bracketed kernel by
-    # kernel, so the same step runs eagerly (identical kernels / shapes) right after the timed region
-    prof = None
-    prof_steps = 0
-    if not args.no_kernel_events and rank == 0 or (not args.no_kernel_events and world > 1):
-        net.cfg.overlap_wgrad = 0              # per-kernel events need a serial timeline
-        K.PROFILE = []
-        for _ in range(args.roofline_steps):
-            runner._eager(X, y)
-            prof_steps += 1
-        torch.cuda.synchronize()
-        prof, K.PROFILE = K.PROFILE, None
+    prof, prof_steps = None, 0
+    if not args.no_kernel_events:              # every rank runs them (the eager steps contain collectives)
+        prof_steps = args.roofline_steps
+        prof = kernel_events(run, prof_steps)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    line = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        flop_img = 3 * 2.0 * net.macs(img)                    # fwd + bwd = 3 x fwd, FLOP = 2 MAC
+        flop_img = run.flop_per_image()
         roof = None
         if prof:
-            fam = {}
-            for name, flops, e0, e1, nbytes in prof:
-                f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
-                f[0] += flops
-                f[1] += e0.elapsed_time(e1) * 1e-3
-                f[2] += 1
-                f[3] += nbytes
-            name, (fl, sec, cnt, nb) = max(fam.items(), key=lambda kv: kv[1][1])
-            traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (profiles/, offline)
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                t = json.load(open(tpath))
-                if t.get("workload_key") == f"{args.arch}-{E}-{img}-{B}-{args.dtype}":
-                    traffic = t.get("hbm_bytes_per_launch", {}).get(name)
-            roof = {"kernel": name, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS
-                    if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": fl / sec / 1e12 /
-                    (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": nb / cnt, "flops_per_launch": fl / cnt,
-                    "launches": cnt, "avg_launch_us": sec / cnt * 1e6,
-                    "measured": f"HIP events around every launch, {prof_steps} eager steps after the timed region",
-                    "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / prof_steps * 1e3,
-                                     "launches_per_step": v[2] / prof_steps} for k, v in fam.items()},
-                    "whole_step_tflops": value / world * flop_img / 1e12}
-        line = {"metric": "images/sec at 513x513 fwd+bwd+SGD step (early-exit DeepLabV3 training)",
+            roof = roofline(prof, prof_steps, args.dtype, f"{args.arch}-{run.E}-{args.img}-{B}-{args.dtype}")
+            roof["whole_step_tflops"] = value / world * flop_img / 1e12
+        line = {"metric": "images/sec at 513x513 B=32 fwd+bwd (+ gradient all-reduce + SGD step), early-exit DeepLabV3 training",
                 "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                 "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": f"DeepLabV3-{args.arch} {E} exits, {img}x{img}, {C} classes, B={B}/GPU, "
-                                       f"{'per-exit CE (sum)' if args.loss == 'ce' else 'raw-logit Lovasz (sum over exits)'}, SGD momentum 0.9 wd 5e-4",
-                           "global_batch": world * B, "parallelism": f"dp{world}", "sync_bn": bool(net.cfg.sync_bn),
-                           "hip_graph": bool(runner.graph is not None), "warmup_steps_run": warmup_run,
-                           "flop_per_image": flop_img, "loss_last_step": loss_val},
+                "config": {"workload": run.workload(), "global_batch": world * B, "batch_per_gpu": B,
+                           "parallelism": f"dp{world}", "sync_bn": bool(run.net.cfg.sync_bn),
+                           "hip_graph": bool(run.runner.graph is not None), "warmup_steps_run": warmup_run,
+                           "flop_per_image": flop_img, "loss_last_step": loss_val,
+                           "splits": list(run.net.split_names)},
                 "roofline": roof}
+    headline = (args.arch, args.branches, args.classes, args.img)
+    del run, prof
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        sec = {}
+        try:
+            # BASELINE configs[1]: R50, 2 exits, 21 classes, B=16 on one GPU (round 1's bench line)
+            r2 = Run("resnet50", 1, 21, 513, 16, "bf16", "ce", False, 1, 0, dev, args)
+            d2, l2, _ = timed(r2, args.steps, args.warmup, 1, 1, args.no_graph)
+            sec["configs1_r50_e2_b16_bf16"] = {"workload": r2.workload(), "value": 16 * args.steps / d2,
+                                               "unit": "images/sec", "ms_per_step": d2 / args.steps * 1e3,
+                                               "whole_step_tflops": 16 * args.steps / d2 * r2.flop_per_image() / 1e12,
+                                               "loss_last_step": l2}
+            del r2
+            gc.collect()
+            torch.cuda.empty_cache()
+            # the headline architecture in the fp32 parity mode (exact-fp32 MFMA; the mode the 1e-3 logit bar holds in)
+            bf = min(B, 8)
+            r3 = Run(headline[0], headline[1], headline[2], headline[3], bf, "f32", "ce", False, 1, 0, dev, args)
+            d3, l3, _ = timed(r3, 3, 0, 1, 1, True)
+            sec["f32_parity_mode"] = {"workload": r3.workload(), "value": bf * 3 / d3, "unit": "images/sec",
+                                      "ms_per_step": d3 / 3 * 1e3, "steps": 3, "hip_graph": False,
+                                      "whole_step_tflops": bf * 3 / d3 * r3.flop_per_image() / 1e12,
+                                      "peak_tflops": PEAK_F32_TFLOPS, "loss_last_step": l3}
+            del r3
+            gc.collect()
+            torch.cuda.empty_cache()
+        except Exception as exc:          # a secondary figure must never cost the headline line
+            sec["error"] = repr(exc)
+        line["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, torch CPU fp32) ...")
-            line["cpu_baseline"] = cpu_baseline(args.arch, args.branches, C, img, 2, 1234)
+            line["cpu_baseline"] = cpu_baseline(headline[0], headline[1], headline[2], headline[3], 2, 1234)
             log("cpu baseline done")
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():

@@ -90,6 +90,7 @@ SIGNATURES = {
     "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "eeseg_argmax_pair_hist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "eeseg_ssim_labels": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),
     "eeseg_lovasz_workspace": (_i64, [_i64, _i]),

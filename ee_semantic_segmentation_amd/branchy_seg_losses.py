@@ -52,11 +52,22 @@ def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=No
 
 
 class LovaszSoftmax(nn.Module):
-    def __init__(self, classes="present", per_image=False, ignore=None, n_branches=0, prev_out=False):
+    """Data-parallel runs: ``per_image=False`` ranks all pixels of the batch JOINTLY (branchy_seg_losses.py:134,154;
+    lovaszsoftmax.py:172-200), so the loss of a sharded batch is not a function of per-shard losses.  The default
+    (`per_shard=False`) is therefore exact: every rank all-gathers the exits' low-resolution logits and the labels
+    (a few MB), evaluates the loss of the WHOLE batch and back-propagates its own images' part (engine.AllGatherRows);
+    the sort is redundant across ranks - that is the price of the reference's joint ranking.  `per_shard=True` ranks
+    each rank's pixels alone (cheaper, a documented deviation).  `comm`: engine.Config whose group is used when the
+    prediction is a plain tensor (an ExitLogits carries its network's)."""
+
+    def __init__(self, classes="present", per_image=False, ignore=None, n_branches=0, prev_out=False, per_shard=False,
+                 comm=None):
         super().__init__()
         self.classes, self.per_image, self.ignore = classes, per_image, ignore
         self.n = n_branches + 1
         self.prev_out = prev_out
+        self.per_shard = per_shard
+        self.comm = comm
         self._set_weights()
 
     def _set_weights(self):
@@ -68,8 +79,20 @@ class LovaszSoftmax(nn.Module):
 
     def forward(self, y_pred, targets):
         losses = []
+        comm = getattr(y_pred, "cfg", None) or self.comm
+        gather = comm is not None and comm.dp_active() and not self.per_shard
+        if gather:
+            t = targets.squeeze(1) if targets.dim() > 3 else targets
+            targets = comm.all_gather(t.contiguous()).flatten(0, 1)
         for i in range(self.n):
-            yi = y_pred[i]            # ExitLogits materialises one exit; a tensor indexes
+            if gather and isinstance(y_pred, ExitLogits):
+                from .from_deepv3_new import upsample_logits
+                lr = E.AllGatherRows.apply(y_pred.lowres[i], comm)
+                yi = upsample_logits(lr, y_pred.num_classes, y_pred.size)
+            elif gather:
+                yi = E.AllGatherRows.apply(y_pred[i], comm)
+            else:
+                yi = y_pred[i]            # ExitLogits materialises one exit; a tensor indexes
             losses.append(lovasz_softmax(yi, targets, self.classes, self.per_image, self.ignore).unsqueeze(0))
         losses = torch.cat(losses)
         if self.prev_out:

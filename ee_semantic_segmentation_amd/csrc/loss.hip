@@ -904,6 +904,82 @@ extern "C" int eeseg_argmax_pair_hist(const float* logits_a, const float* logits
     return EESEG_OK;
 }
 
+// ------------------------------------------------------------------ SSIM ----
+// Structural similarity of two integer LABEL maps (sim_metrics.py:15-37 -> skimage.metrics.structural_similarity with
+// its defaults: 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03, mean over the image cropped by 3 pixels
+// per side, float64 arithmetic).  Window sums of a, b, a*a, b*b, a*b are exact integers; one thread per output pixel,
+// the (16+6)^2 label patch of both maps staged in LDS; per-image sums of S reduced in double.
+#define SSIM_T 16
+#define SSIM_W 7
+__global__ __launch_bounds__(SSIM_T* SSIM_T) void ssim_labels_kernel(const long long* __restrict__ a,
+                                                                      const long long* __restrict__ b, int H, int W,
+                                                                      double c1, double c2, double* sums) {
+    __shared__ int pa[SSIM_T + SSIM_W - 1][SSIM_T + SSIM_W];
+    __shared__ int pb[SSIM_T + SSIM_W - 1][SSIM_T + SSIM_W];
+    __shared__ double red[SSIM_T * SSIM_T / 64];
+    const int n = blockIdx.z;
+    const int Ho = H - (SSIM_W - 1), Wo = W - (SSIM_W - 1);       // interior outputs (the crop)
+    const int oy0 = blockIdx.y * SSIM_T, ox0 = blockIdx.x * SSIM_T;
+    const long long* an = a + (size_t)n * H * W;
+    const long long* bn = b + (size_t)n * H * W;
+    const int P = SSIM_T + SSIM_W - 1;
+    for (int i = threadIdx.x; i < P * P; i += SSIM_T * SSIM_T) {
+        const int r = i / P, c = i - r * P;
+        const int y = oy0 + r, x = ox0 + c;
+        const bool in = y < H && x < W;
+        pa[r][c] = in ? (int)an[(size_t)y * W + x] : 0;
+        pb[r][c] = in ? (int)bn[(size_t)y * W + x] : 0;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / SSIM_T, tx = threadIdx.x - ty * SSIM_T;
+    double s = 0.0;
+    if (oy0 + ty < Ho && ox0 + tx < Wo) {
+        int sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+#pragma unroll
+        for (int r = 0; r < SSIM_W; ++r)
+#pragma unroll
+            for (int c = 0; c < SSIM_W; ++c) {
+                const int va = pa[ty + r][tx + c], vb = pb[ty + r][tx + c];
+                sa += va; sb += vb; saa += va * va; sbb += vb * vb; sab += va * vb;
+            }
+        const double np_ = (double)(SSIM_W * SSIM_W), cov = np_ / (np_ - 1.0);
+        const double ux = sa / np_, uy = sb / np_;
+        const double vx = cov * (saa / np_ - ux * ux), vy = cov * (sbb / np_ - uy * uy), vxy = cov * (sab / np_ - ux * uy);
+        s = ((2.0 * ux * uy + c1) * (2.0 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < SSIM_T * SSIM_T / 64; ++i) t += red[i];
+        atomicAdd(&sums[n], t);
+    }
+}
+
+__global__ void ssim_finish_kernel(double* sums, int N, double inv_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) sums[i] *= inv_count;
+}
+
+extern "C" int eeseg_ssim_labels(const int64_t* labels_a, const int64_t* labels_b, int N, int H, int W, double data_range,
+                                 double* ssim_out, void* stream) {
+    EESEG_CHECK(labels_a && labels_b && ssim_out, EESEG_ERR_ARG, "ssim_labels: null pointer");
+    EESEG_CHECK(N >= 1 && H >= SSIM_W && W >= SSIM_W, EESEG_ERR_ARG, "ssim_labels: image smaller than the 7x7 window");
+    EESEG_CHECK(data_range > 0, EESEG_ERR_ARG, "ssim_labels: data_range must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    EESEG_HIP(hipMemsetAsync(ssim_out, 0, sizeof(double) * N, st));
+    const int Ho = H - (SSIM_W - 1), Wo = W - (SSIM_W - 1);
+    const double c1 = (0.01 * data_range) * (0.01 * data_range), c2 = (0.03 * data_range) * (0.03 * data_range);
+    hipLaunchKernelGGL(ssim_labels_kernel, dim3((Wo + SSIM_T - 1) / SSIM_T, (Ho + SSIM_T - 1) / SSIM_T, N),
+                       dim3(SSIM_T * SSIM_T), 0, st, (const long long*)labels_a, (const long long*)labels_b, H, W, c1, c2,
+                       ssim_out);
+    EESEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, st, ssim_out, N, 1.0 / ((double)Ho * Wo));
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
 extern "C" int64_t eeseg_entropy_gate_workspace(int N, int H, int W) {
     return (int64_t)N * H * W * (int64_t)sizeof(float);
 }

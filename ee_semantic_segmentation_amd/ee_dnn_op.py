@@ -5,7 +5,8 @@ non-ignored branch only provides the reference label map; every later one exits 
 ``last_flops_2``; the ``_2`` variants leave out the first evaluated branch, ee_dnn_op.py:88-90).  FLOPs come from
 the analytic conv-MAC counter; the two label maps are compared through the on-device contingency table of
 ``eeseg_argmax_pair_hist`` (low-res logits of both exits in, one C x C int table out).  ``metric`` is a function
-of that table: use ``eval_br_sim.gate_function(name, ignore)[0]`` or any ``sim_metrics.*_from_table``.
+of that table: use ``eval_br_sim.gate_function(name, ignore)[0]`` or any ``sim_metrics.*_from_table``; a
+``sim_metrics.SSIM`` instance is evaluated on the two label maps (``eeseg_ssim_labels``).
 ``stop_at_exit=True`` really stops after the exit; by default the backbone is finished and ``last``
 is reported, like the reference."""
 import torch
@@ -13,6 +14,7 @@ import torch
 from . import kernels as K
 from .ee_dnn_op_ne import section_flops
 from .from_deepv3_new import head_macs
+from .sim_metrics import SSIM
 
 
 class eval_ee_deeplabv3:
@@ -45,7 +47,11 @@ class eval_ee_deeplabv3:
                 lr = self.model.branches[i](x).contiguous()
                 branch_flops.append(2 * head_macs(self.model.branches[i], h, w))
                 similar = False
-                if ref_lr is not None:
+                if ref_lr is not None and isinstance(self.metric, SSIM):
+                    maps = [K.argmax_confusion(l, C, None, H, W, want_pred=True)[1] for l in (ref_lr, lr)]
+                    t = float(K.ssim_labels(maps[0], maps[1], self.metric.dr)[0])
+                    similar = (t < self.threshold) if self.less_than else (t > self.threshold)
+                elif ref_lr is not None:
                     t = self.metric(K.argmax_pair_hist(ref_lr, lr, C, H, W)[0].double())
                     similar = (t < self.threshold) if self.less_than else (t > self.threshold)
                 if similar:

@@ -31,6 +31,8 @@ class Config:
         self.compute_dtype = torch.float32   # torch.bfloat16 = throughput mode
         self.sync_bn = False                 # all-reduce BN statistics over the process group
         self.group = None
+        self.collective = None               # test hook: callable(tensor, group) used instead of dist.all_reduce
+        self.gatherer = None                 # test hook: callable(tensor, group) -> [world, *tensor.shape]
         self.dropout_seed = 0x5EED
         self._drop_calls = 0
         self.arena = None                    # GradArena: parameter gradients written in place
@@ -50,9 +52,37 @@ class Config:
         return dist.get_world_size(self.group)
 
     def sync_active(self):
+        return self.sync_bn and self.dp_active()
+
+    def dp_world(self):
+        """Ranks of the data-parallel group (independent of sync_bn): the CE valid-pixel count and the exact
+        Lovasz mode are always global over it."""
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def dp_active(self):
         import os
-        return self.sync_bn and dist.is_initialized() and (
+        return dist.is_initialized() and (
             dist.get_world_size(self.group) > 1 or os.environ.get("EESEG_FORCE_ALLREDUCE") == "1")
+
+    def dp_rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def all_gather(self, t):
+        """-> [world, *t.shape]: `t` of every rank of the data-parallel group, in rank order."""
+        if self.gatherer is not None:
+            return self.gatherer(t, self.group)
+        out = torch.empty((self.dp_world(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+    def all_reduce(self, t):
+        """Sum `t` over the data-parallel group in place.  `collective` (callable(t, group)) replaces
+        torch.distributed's call; the world-2 parity tests use it to stage device tensors through gloo."""
+        if self.collective is not None:
+            self.collective(t, self.group)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
 
     def next_seed(self):
         self._drop_calls += 1
@@ -151,7 +181,7 @@ class GradArena:
             elif what == "cls_w":
                 co, ci = obj.shape[0], obj.shape[1]
                 self.kernel_view[obj] = seg.view(CPAD, 1, 1, ci)
-                obj.grad = seg[:co * ci].view(co, 1, 1, ci).permute(0, 3, 1, 2)
+                obj.grad = self._grad_like(seg, obj)
             elif what == "cls_b":
                 self.kernel_view[obj] = seg
                 obj.grad = seg[:obj.numel()]
@@ -164,7 +194,17 @@ class GradArena:
                     raise RuntimeError("GradArena needs channels_last conv weights")
                 kv = seg.view(co, r, s_, ci)
                 self.kernel_view[obj] = kv
-                obj.grad = kv.permute(0, 3, 1, 2)
+                obj.grad = self._grad_like(seg, obj)
+
+    @staticmethod
+    def _grad_like(seg, p):
+        """View of the arena segment with EXACTLY the parameter's shape and strides.  torch leaves the strides of
+        size-1 dims arbitrary (a [Co,Ci,1,1] channels_last weight keeps (Ci,1,1,1)), so a permuted KRSC view can differ
+        from the parameter in those dims although the bytes are laid out identically; the fused SGD step indexes raw
+        memory and must see the arena itself, never a copy."""
+        if not p.permute(0, 2, 3, 1).is_contiguous():
+            raise RuntimeError("GradArena needs conv weights whose physical order is KRSC (channels_last)")
+        return torch.as_strided(seg, p.shape, p.stride())
 
     @staticmethod
     def _block_entries(b):
@@ -244,28 +284,69 @@ def _geom(conv):
     return conv.stride[0], conv.padding[0], conv.dilation[0]
 
 
+class AllGatherRows(torch.autograd.Function):
+    """[n, ...] on every rank -> [world*n, ...] (rank-major) on every rank.  For losses that every rank evaluates
+    on the WHOLE batch (exact Lovasz): each rank then holds the full gradient, so backward just takes this rank's
+    rows, times world because the data-parallel reducer averages the parameter gradients over the ranks."""
+
+    @staticmethod
+    def forward(ctx, t, cfg):
+        ctx.cfg, ctx.n = cfg, t.shape[0]
+        return cfg.all_gather(t.contiguous()).flatten(0, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg, n = ctx.cfg, ctx.n
+        r = cfg.dp_rank()
+        return g[r * n:(r + 1) * n] * float(cfg.dp_world()), None
+
+
 def _allreduce(cfg, t):
     if cfg.sync_active():
-        dist.all_reduce(t, group=cfg.group)
+        cfg.all_reduce(t)
     return t
 
 
+def sync_bn_sums(cfg, sums, count):
+    """SyncBN forward: `sums` [2,C] = this rank's (sum x, sum x^2) over `count` samples per channel ->
+    the group's sums (in place) and the group's sample count.  Every rank holds the same number of samples
+    (equal shards), so the count is count * world."""
+    cfg.all_reduce(sums)
+    return sums, count * cfg.world()
+
+
+def global_mean_normaliser(comm, cnt):
+    """Per-exit valid-pixel counts `cnt` [E] of this rank's shard -> the divisor that makes the AVERAGE over
+    ranks of (rank loss sum / divisor) equal to the whole batch's mean loss: (sum of the counts over the group)
+    / world.  Gradients are averaged over ranks the same way (parallel.ArenaReducer)."""
+    tot = cnt.clone()
+    comm.all_reduce(tot)
+    return tot / comm.dp_world()
+
+
 # ------------------------------------------------------- conv + BN (+ReLU) ----
-def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False):
-    """Train-mode conv -> BN(batch stats) -> (+residual) -> ReLU.  Returns (y, state)."""
+def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False, frozen=False):
+    """Train-mode conv -> BN(batch stats) -> (+residual) -> ReLU.  Returns (y, state).
+    `frozen`: differentiable EVAL-mode BatchNorm (running statistics, not updated): what torch does when a
+    network in .eval() is back-propagated (fine-tuning with frozen statistics)."""
     if x_is_col:      # stem GEMM: x is the im2col matrix, weight is the padded [Cout,1,1,Kpad] matrix
         wf = packed_stem(conv, x.dtype, x.shape[-1])
-        c, part = K.conv_fwd(x, wf, want_stats=True)
+        c, part = K.conv_fwd(x, wf, want_stats=not frozen)
     else:
         wf, _ = packed(conv, x.dtype)
         s, p, d = _geom(conv)
-        c, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
+        c, part = K.conv_fwd(x, wf, s, p, d, want_stats=not frozen)
     count = c.numel() // c.shape[-1]
     mom = bn.momentum if bn.momentum is not None else 0.1
+    if frozen:
+        ss = K.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        mi = torch.stack([bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)])
+        if residual is not None and relu:
+            y, mask = K.bn_apply(c, ss, residual=residual, relu=True, out=out, want_mask=True)
+            return y, (x, c, mask, mi, count, relu, ss, True)
+        return K.bn_apply(c, ss, residual=residual, relu=relu, out=out), (x, c, None, mi, count, relu, ss, True)
     if cfg.sync_active():
-        sums = K.reduce_partials(part)
-        _allreduce(cfg, sums)
-        count *= cfg.world()
+        sums, count = sync_bn_sums(cfg, K.reduce_partials(part), count)
         mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
     elif part.shape[0] > 2048:      # very many tiles (stem): two-level reduction, then finalize
         mi, ss = K.bn_finalize(K.reduce_partials(part), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean,
@@ -285,7 +366,8 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False)
 def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):
     """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
     parameter gradients are None in arena mode (written in place)."""
-    x, c, y, mi, count, relu, ss = st
+    x, c, y, mi, count, relu, ss = st[:7]
+    frozen = len(st) > 7 and st[7]
     pair = cfg.gview(bn)
     if pair is not None and cfg.accumulate:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
@@ -293,7 +375,10 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     else:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
-    if cfg.sync_active():
+    if frozen:
+        # statistics are constants: dc = g * gamma * invstd, i.e. the train-mode formula without its two mean terms
+        sums = torch.zeros_like(sums)
+    elif cfg.sync_active():
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
         sums = sums.clone() if pair is not None else sums
@@ -389,7 +474,7 @@ STEM_KPAD = 192     # 7*7*3 = 147 -> multiple of 64
 
 
 # ------------------------------------------------------------------- stem ----
-def stem_fwd(cfg, img, conv, bn, train):
+def stem_fwd(cfg, img, conv, bn, train, frozen=False):
     """img [N,3,H,W] fp32 NCHW -> [N,H/4,W/4,64] NHWC in compute dtype."""
     if not img.is_contiguous():
         img = img.contiguous()
@@ -397,8 +482,8 @@ def stem_fwd(cfg, img, conv, bn, train):
         img = img.float()
     r = conv.weight.shape[2]
     col = K.im2col_nchw(img, r, r, conv.stride[0], conv.padding[0], STEM_KPAD, cfg.compute_dtype)
-    if train:
-        y, st = conv_bn_fwd(cfg, col, conv, bn, True, x_is_col=True)
+    if train or frozen:
+        y, st = conv_bn_fwd(cfg, col, conv, bn, True, x_is_col=True, frozen=frozen)
     else:
         y, st = conv_bn_eval(cfg, col, conv, bn, True, x_is_col=True), None
     p = K.maxpool3x3s2(y)
@@ -413,21 +498,21 @@ def stem_bwd(cfg, state, dp, conv, bn):
 
 
 # ------------------------------------------------------------- bottleneck ----
-def bottleneck_fwd(cfg, x, blk, train):
+def bottleneck_fwd(cfg, x, blk, train, frozen=False):
     ds = blk.downsample
-    if not train:
+    if not train and not frozen:
         y1 = conv_bn_eval(cfg, x, blk.conv1, blk.bn1, True)
         y2 = conv_bn_eval(cfg, y1, blk.conv2, blk.bn2, True)
         idn = conv_bn_eval(cfg, x, ds[0], ds[1], False) if ds is not None else x
         return conv_bn_eval(cfg, y2, blk.conv3, blk.bn3, True, residual=idn), None
-    y1, s1 = conv_bn_fwd(cfg, x, blk.conv1, blk.bn1, True)
-    y2, s2 = conv_bn_fwd(cfg, y1, blk.conv2, blk.bn2, True)
+    y1, s1 = conv_bn_fwd(cfg, x, blk.conv1, blk.bn1, True, frozen=frozen)
+    y2, s2 = conv_bn_fwd(cfg, y1, blk.conv2, blk.bn2, True, frozen=frozen)
     sd = None
     if ds is not None:
-        idn, sd = conv_bn_fwd(cfg, x, ds[0], ds[1], False)
+        idn, sd = conv_bn_fwd(cfg, x, ds[0], ds[1], False, frozen=frozen)
     else:
         idn = x
-    out, s3 = conv_bn_fwd(cfg, y2, blk.conv3, blk.bn3, True, residual=idn)
+    out, s3 = conv_bn_fwd(cfg, y2, blk.conv3, blk.bn3, True, residual=idn, frozen=frozen)
     return out, (s1, s2, s3, sd)
 
 
@@ -458,7 +543,7 @@ def conv_bias_fwd(cfg, x, conv):
     return K.conv_fwd(x, wf, s, p, d, shift=conv.bias.detach())[0]
 
 
-def conv_bias_bwd(cfg, x, dy, conv):
+def conv_bias_bwd(cfg, x, dy, conv, dx_accum=None):
     """-> (dx, dw, dbias); dw/dbias are None when they were written into the gradient arena."""
     gvw, gvb = cfg.gview(conv.weight), cfg.gview(conv.bias)
     r = conv.weight.shape[2]
@@ -474,12 +559,14 @@ def conv_bias_bwd(cfg, x, dy, conv):
         db = K.colsum(dy)
         dw = K.conv_wgrad(x, dy, r, r, s, p, d).permute(0, 3, 1, 2)
     _, wb = packed(conv, x.dtype)
-    dx = K.conv_dgrad(dy, wb, x.shape[1:3], s, p, d)
+    dx = K.conv_dgrad(dy, wb, x.shape[1:3], s, p, d, accumulate_into=dx_accum)
     return dx, dw, db
 
 
-def head_fwd(cfg, x, head, train):
-    """DeepLabHead on NHWC features -> low-res logits [N,h,w,CPAD] fp32."""
+def head_fwd(cfg, x, head, train, frozen=False):
+    """DeepLabHead on NHWC features -> low-res logits [N,h,w,CPAD] fp32.  `frozen`: differentiable eval mode
+    (running statistics, no dropout), state saved for head_bwd."""
+    keep = train or frozen
     aspp = head.aspp
     x_in = x
     if head.pre is not None:
@@ -492,31 +579,31 @@ def head_fwd(cfg, x, head, train):
     for i in range(nb - 1):
         seq = aspp.convs[i]
         sl = cat[..., i * mid:(i + 1) * mid]
-        if train:
-            _, st = conv_bn_fwd(cfg, x, seq[0], seq[1], True, out=sl)
+        if keep:
+            _, st = conv_bn_fwd(cfg, x, seq[0], seq[1], True, out=sl, frozen=frozen)
             states.append(st)
         else:
             conv_bn_eval(cfg, x, seq[0], seq[1], True, out=sl)
     # image pooling branch: GAP -> 1x1 conv -> BN -> ReLU -> broadcast
     pool = aspp.convs[nb - 1]
     g = K.sum_hw(x, 1.0 / (h * w)).view(N, 1, 1, cin)
-    if train:
-        pv, stp = conv_bn_fwd(cfg, g, pool[1], pool[2], True)
+    if keep:
+        pv, stp = conv_bn_fwd(cfg, g, pool[1], pool[2], True, frozen=frozen)
         states.append(stp)
     else:
         pv = conv_bn_eval(cfg, g, pool[1], pool[2], True)
     K.broadcast_hw(pv.view(N, mid), cat[..., (nb - 1) * mid:])
     proj = aspp.project
     seed = None
-    if train:
-        pr, stj = conv_bn_fwd(cfg, cat, proj[0], proj[1], True)
-        pdrop = proj[3].p
+    if keep:
+        pr, stj = conv_bn_fwd(cfg, cat, proj[0], proj[1], True, frozen=frozen)
+        pdrop = 0.0 if frozen else proj[3].p
         if pdrop > 0:
             seed = cfg.next_seed()
             pr_d = K.dropout(pr, pdrop, seed, cfg.step_dev(pr.device))
         else:
             pr_d = pr
-        q, stq = conv_bn_fwd(cfg, pr_d, head.conv3, head.bn3, True)
+        q, stq = conv_bn_fwd(cfg, pr_d, head.conv3, head.bn3, True, frozen=frozen)
     else:
         pr_d = conv_bn_eval(cfg, cat, proj[0], proj[1], True)
         q = conv_bn_eval(cfg, pr_d, head.conv3, head.bn3, True)
@@ -533,12 +620,13 @@ def head_fwd(cfg, x, head, train):
         bias = (bkey, bp)
         cls.__dict__["_eeseg_bias_pad"] = bias
     logits, _ = K.conv_fwd(q32, wf, shift=bias[1])
-    state = (x, cat, states, stj, seed, stq, q32, x_in) if train else None
+    state = (x, cat, states, stj, seed, stq, q32, x_in) if keep else None
     return logits, state
 
 
-def head_bwd(cfg, state, dlogits, head):
-    """Returns (dx, grads in head.param_list() order)."""
+def head_bwd(cfg, state, dlogits, head, dx_init=None):
+    """Returns (dx, grads in head.param_list() order).  `dx_init`: a gradient of the head's input that already
+    exists (the next backbone section's, nn_modules._HeadForkFn); the head's gradient is added into it in place."""
     x, cat, states, stj, seed, stq, q32, x_in = state
     aspp = head.aspp
     nb = len(aspp.convs)
@@ -568,7 +656,7 @@ def head_bwd(cfg, state, dlogits, head):
     dpr = K.dropout(dpr_d, proj[3].p, seed, cfg.step_dev(dpr_d.device)) if seed is not None else dpr_d
     dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
     grads_convs = []
-    dx = None
+    dx = dx_init if head.pre is None else None
     for i in range(nb - 1):
         seq = aspp.convs[i]
         sl = dcat[..., i * mid:(i + 1) * mid]
@@ -581,7 +669,7 @@ def head_bwd(cfg, state, dlogits, head):
     grads_convs += [dwp, dgp, dbp]
     grads = grads_convs + [dwj, dgj, dbj, dw3, dg3, db3, dwc, dbias]
     if head.pre is not None:
-        dx, dwpre, dbpre = conv_bias_bwd(cfg, x_in, dx, head.pre)
+        dx, dwpre, dbpre = conv_bias_bwd(cfg, x_in, dx, head.pre, dx_accum=dx_init)
         grads += [dwpre, dbpre]
     cfg.unit_done(head)
     return dx, grads

@@ -3,7 +3,8 @@ maps of exits i-1 and i are similar enough (MSE / VI / H(X|Y) / H(Y|X) below tau
 value comes from the per-image contingency table built on the device by ``eeseg_argmax_pair_hist`` for the
 whole batch at once; the reference moves both full-resolution score tensors to the CPU per image and branch.
 Result keys as the reference: ``b{i}_mIoU``, ``b{i}_count``, ``mIoU_out``, ``count_out``, ``mIoU_gl``,
-``out_gl``, ``t``.  ``metric='ssim'`` is not available (see sim_metrics.py)."""
+``out_gl``, ``t``.  ``metric='ssim'`` (eval_br_sim.py:20-21: ``M.SSIM(n_classes - 1)``) compares the two label maps
+with the windowed ``eeseg_ssim_labels`` kernel instead of the table."""
 import math
 
 import torch
@@ -20,7 +21,7 @@ def gate_function(metric, ignore=()):
     """-> (f(table) -> float, larger_is_similar) for a metric name of eval_br_sim.py:20-31."""
     m = metric.lower()
     if m == "ssim":
-        raise NotImplementedError("SSIM of label images is not a function of the contingency table; not provided")
+        raise ValueError("SSIM is not a function of the contingency table: br_evaluator handles it on the label maps")
     if m == "nmi":
         return M.nmi_from_table, True
     if m == "vi":
@@ -35,7 +36,8 @@ def gate_function(metric, ignore=()):
 def br_evaluator(net, n_exits, n_classes, test_loader, device, metric, tau, ignore=(), skip=0):
     accumulator = [mIoU(n_classes=n_classes, device=device) for _ in range(n_exits + 1)]
     out_count = [0 for _ in range(n_exits + 1)]
-    f, larger = gate_function(metric, ignore)
+    ssim = M.SSIM(n_classes - 1) if metric.lower() == "ssim" else None          # eval_br_sim.py:20-21
+    f, larger = (None, True) if ssim is not None else gate_function(metric, ignore)
     n_branches = n_exits - 1
     with torch.no_grad():
         for X, y in test_loader:
@@ -47,7 +49,10 @@ def br_evaluator(net, n_exits, n_classes, test_loader, device, metric, tau, igno
             pairs = list(range(1 + skip, n_branches))
             tables = {}
             for i in pairs:
-                if fused:
+                if ssim is not None:      # [B] SSIM values of the pair's label maps, computed on the device
+                    tables[i] = ssim.device_value(y_pred if fused else y_pred[i - 1], y_pred if fused else y_pred[i],
+                                                  i - 1 if fused else None, i if fused else None)
+                elif fused:
                     tables[i] = K.argmax_pair_hist(y_pred.lowres[i - 1].contiguous(), y_pred.lowres[i].contiguous(),
                                                    n_classes, *y_pred.size)
                 else:
@@ -57,7 +62,7 @@ def br_evaluator(net, n_exits, n_classes, test_loader, device, metric, tau, igno
                 left = False
                 yb = y[b:b + 1]
                 for i in pairs:
-                    t = f(tables[i][b])
+                    t = float(tables[i][b]) if ssim is not None else f(tables[i][b])
                     if (t > tau) if larger else (t < tau):
                         pb = _one_image(y_pred, i, b)
                         accumulator[i](pb, yb, 0)

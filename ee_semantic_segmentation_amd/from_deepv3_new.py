@@ -105,10 +105,11 @@ class ExitLogits:
     ``stack()`` materialises the reference's ``[E,B,C,H,W]`` tensor; ``y[i]``
     materialises one exit.  Fused consumers use ``.lowres`` directly."""
 
-    def __init__(self, lowres, num_classes, size):
+    def __init__(self, lowres, num_classes, size, cfg=None):
         self.lowres = list(lowres)          # E x [B,h,w,32] fp32
         self.num_classes = num_classes
         self.size = tuple(size)
+        self.cfg = cfg                      # engine.Config of the producing network (process group of the losses)
 
     def __len__(self):
         return len(self.lowres)
@@ -302,13 +303,14 @@ class branchyDeepv3(nn.Module):
         outs = []
         for i in range(self.n_branches):
             X = self.base_model[i](X)
-            outs.append(self.branches[i](X))
+            lo, X = self.branches[i].forward_fork(X)
+            outs.append(lo)
         outs.append(self.classifier(self.base_model[-1](X)))
         return outs
 
     def forward(self, X):
         size = X.shape[-2:]
-        el = ExitLogits(self.forward_lowres(X), self.num_classes, size)
+        el = ExitLogits(self.forward_lowres(X), self.num_classes, size, self.cfg)
         if self.fused_outputs:
             return el
         return el.stack()

@@ -80,19 +80,29 @@ def _prof_begin():
     return ev
 
 
-def _prof_end(ev, family, flops, nbytes=0.0):
+def _prof_end(ev, family, flops, nbytes=0.0, tag=""):
     if ev is None:
         return
     end = torch.cuda.Event(enable_timing=True)
     end.record()
-    PROFILE.append((family, flops, ev, end, nbytes))
+    PROFILE.append((family, flops, ev, end, nbytes, tag))
+
+
+_ws_retired = []     # superseded scratch buffers: a captured HIP graph may still hold their addresses
 
 
 def workspace(nbytes, device):
+    """Shared scratch of the reduction / loss / gate kernels.  It only ever grows (geometrically, so the retired
+    buffers sum to less than the live one) and a superseded buffer is never freed: the address of the buffer in use at
+    capture time is baked into GraphedTrainStep's graph, and a replay must not scribble over memory the caching
+    allocator has handed to somebody else in the meantime."""
     key = str(device)
     t = _ws.get(key)
     if t is None or t.numel() < nbytes:
-        t = torch.empty(max(int(nbytes), 1 << 24), dtype=torch.uint8, device=device)
+        if t is not None:
+            _ws_retired.append(t)
+        t = torch.empty(max(int(nbytes), 1 << 24, 2 * t.numel() if t is not None else 0), dtype=torch.uint8,
+                        device=device)
         _ws[key] = t
     return t
 
@@ -150,7 +160,8 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
             fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
         es = 2 if a.dtype == BF16 else 4       # algorithmic bytes: every operand once
         _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S,
-                  float(es) * (N * Hin * Win * Cin + Cout * R * S * Cin + N * Hout * Wout * Cout))
+                  float(es) * (N * Hin * Win * Cin + Cout * R * S * Cin + N * Hout * Wout * Cout),
+                  f"{R}x{S} {'dgrad' if (sdiv > 1 or tstep < 0) else 'fwd'} {Cin}->{Cout} d{abs(tstep)}")
 
 
 def conv_fwd(x, w, stride=1, pad=0, dil=1, *, want_stats=False, scale=None, shift=None, residual=None,
@@ -222,7 +233,8 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
         es = 2 if a.dtype == BF16 else 4
         _prof_end(ev, f"conv_wgrad_kernel<{'bf16' if a.dtype == BF16 else 'f32'}>",
                   2.0 * N * Ho * Wo * Cout * Cin * R * S,
-                  float(es) * (N * H * W * Cin + N * Ho * Wo * Cout) + 4.0 * Cout * R * S * Cin)
+                  float(es) * (N * H * W * Cin + N * Ho * Wo * Cout) + 4.0 * Cout * R * S * Cin,
+                  f"{R}x{S} wgrad {Cin}->{Cout} d{dil}")
     return out
 
 
@@ -558,6 +570,17 @@ def argmax_pair_hist(lr_a, lr_b, C_, H, W, hist=None):
     check(lib().eeseg_argmax_pair_hist(_p(lr_a), _p(lr_b), ldc, N, C_, h, w, H, W, _p(hist), _stream()),
           "eeseg_argmax_pair_hist")
     return hist
+
+
+def ssim_labels(a, b, data_range):
+    """a, b [N,H,W] int64 label maps -> [N] float64 mean SSIM (7x7 uniform window, skimage defaults)."""
+    _need_cuda(a, b)
+    assert a.shape == b.shape and a.dim() == 3 and a.dtype == b.dtype == torch.int64
+    a, b = a.contiguous(), b.contiguous()
+    N, H, W = a.shape
+    out = torch.empty((N,), dtype=torch.float64, device=a.device)
+    check(lib().eeseg_ssim_labels(_p(a), _p(b), N, H, W, float(data_range), _p(out), _stream()), "eeseg_ssim_labels")
+    return out
 
 
 def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1):

@@ -7,7 +7,6 @@ loss kernel so the stacked tensor is never materialised).  Fixes B-6
 (``update_n``) and B-7 (squeeze only the channel dim of the targets).
 """
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from . import engine as E
@@ -25,21 +24,18 @@ def _as_lowres(y, C):
 
 class _FusedCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, target, C, H, W, ignore_index, mean, sync, *lrs):
+    def forward(ctx, target, C, H, W, ignore_index, mean, comm, *lrs):
         dev = lrs[0].device
         accum = torch.zeros((len(lrs), 2), dtype=torch.float64, device=dev)
         lrs = [lr.contiguous() for lr in lrs]
         for e, lr in enumerate(lrs):
             K.upsample_ce_fwd(lr, C, target, H, W, ignore_index, accum[e])
         if mean:
-            import os
-            if sync and dist.is_initialized() and (dist.get_world_size() > 1 or
-                                                   os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"):
+            if comm is not None and comm.dp_active():
                 # global valid-pixel count so that the DP average of the per-rank losses is
-                # the single-device loss of the whole batch
-                cnt = accum[:, 1].clone()
-                dist.all_reduce(cnt)
-                accum[:, 1] = cnt / dist.get_world_size()
+                # the single-device loss of the whole batch; same group as the
+                # gradient average and SyncBN (engine.Config.group)
+                accum[:, 1] = E.global_mean_normaliser(comm, accum[:, 1])
         else:
             accum[:, 1] = 1.0
         ctx.save_for_backward(target, accum, *lrs)
@@ -59,9 +55,18 @@ class _FusedCE(torch.autograd.Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
-def fused_cross_entropy(lowres, target, num_classes, size, ignore_index=-100, reduction="mean", sync=True):
+def _default_comm(group=None):
+    c = E.Config()
+    c.group = group
+    return c
+
+
+def fused_cross_entropy(lowres, target, num_classes, size, ignore_index=-100, reduction="mean", comm=None):
     """Per-exit CrossEntropyLoss(reduction, ignore_index) of bilinearly upsampled
-    low-res logits.  Returns a [E] fp32 tensor."""
+    low-res logits.  Returns a [E] fp32 tensor.  `comm`: the engine.Config whose process group the
+    valid-pixel count is summed over (None = the default group)."""
+    if comm is None:
+        comm = _default_comm()
     if reduction not in ("mean", "sum"):
         raise ValueError("fused cross entropy supports reduction 'mean' or 'sum'")
     if target.dim() > 3:
@@ -70,22 +75,24 @@ def fused_cross_entropy(lowres, target, num_classes, size, ignore_index=-100, re
     if target.dtype != torch.int64:
         target = target.long()
     H, W = size
-    return _FusedCE.apply(target, num_classes, H, W, int(ignore_index), reduction == "mean", sync, *lowres)
+    return _FusedCE.apply(target, num_classes, H, W, int(ignore_index), reduction == "mean", comm, *lowres)
 
 
 class _cross_entropy(nn.Module):
-    def __init__(self, reduction="mean", ignore_index=-100):
+    def __init__(self, reduction="mean", ignore_index=-100, group=None):
         super().__init__()
         self.reduction, self.ignore_index = reduction, ignore_index
+        self.group = group           # process group of the valid-pixel count when y_pred is a plain tensor
 
     def _exit_losses(self, y_pred, targets, n):
         if isinstance(y_pred, ExitLogits):
+            comm = y_pred.cfg if y_pred.cfg is not None else _default_comm(self.group)
             return fused_cross_entropy(y_pred.lowres[:n], targets, y_pred.num_classes, y_pred.size,
-                                       self.ignore_index, self.reduction)
+                                       self.ignore_index, self.reduction, comm)
         ys = [y_pred] if y_pred.dim() == 4 else [y_pred[i] for i in range(n)]
         C = ys[0].shape[1]
         return fused_cross_entropy([_as_lowres(y, C) for y in ys], targets, C, ys[0].shape[-2:], self.ignore_index,
-                                   self.reduction)
+                                   self.reduction, _default_comm(self.group))
 
     def _compute_loss(self, y_pred, targets):
         return self._exit_losses(y_pred, targets, 1)[0]
@@ -95,8 +102,8 @@ class _cross_entropy(nn.Module):
 
 
 class BrXEntropyLoss(_cross_entropy):
-    def __init__(self, reduction="mean", ignore_index=-100, b_reduction="mean", n_exits=0, weights=None):
-        super().__init__(reduction, ignore_index)
+    def __init__(self, reduction="mean", ignore_index=-100, b_reduction="mean", n_exits=0, weights=None, group=None):
+        super().__init__(reduction, ignore_index, group)
         self.b_reduction = b_reduction
         self.n_exits = n_exits
         if weights and len(weights) == n_exits:

@@ -111,8 +111,8 @@ def _needs_grad(*tensors):
 # ----------------------------------------------------------------- stem ------
 class _StemFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, w, g, b, conv, bn, cfg, section):
-        out, st = E.stem_fwd(cfg, img, conv, bn, True)
+    def forward(ctx, img, w, g, b, conv, bn, cfg, section, frozen=False):
+        out, st = E.stem_fwd(cfg, img, conv, bn, not frozen, frozen=frozen)
         ctx.st, ctx.mods, ctx.cfg, ctx.section = st, (conv, bn), cfg, section
         return out
 
@@ -122,12 +122,12 @@ class _StemFn(torch.autograd.Function):
         dw, dg, db = E.stem_bwd(ctx.cfg, ctx.st, dout.contiguous(), conv, bn)
         ctx.st = None
         ctx.cfg.unit_done(ctx.section)
-        return None, dw, dg, db, None, None, None, None
+        return None, dw, dg, db, None, None, None, None, None
 
 
 def run_stem(cfg, img, conv, bn, train, section=None):
-    if train and _needs_grad(conv.weight, bn.weight, bn.bias):
-        return _StemFn.apply(img, conv.weight, bn.weight, bn.bias, conv, bn, cfg, section)
+    if _needs_grad(conv.weight, bn.weight, bn.bias):       # eval mode + autograd = frozen statistics
+        return _StemFn.apply(img, conv.weight, bn.weight, bn.bias, conv, bn, cfg, section, not train)
     with torch.no_grad():
         return E.stem_fwd(cfg, img, conv, bn, train)[0]
 
@@ -136,7 +136,7 @@ def run_stem(cfg, img, conv, bn, train, section=None):
 class _BottleneckFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, cfg, *params):
-        out, st = E.bottleneck_fwd(cfg, x, blk, True)
+        out, st = E.bottleneck_fwd(cfg, x, blk, blk.training, frozen=not blk.training)
         ctx.st, ctx.blk, ctx.cfg = st, blk, cfg
         return out
 
@@ -175,16 +175,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         cfg = self.__dict__["cfg"]
         ps = self.param_list()
-        if self.training and _needs_grad(x, *ps):
+        if _needs_grad(x, *ps):        # .eval() + autograd: BatchNorm uses (and keeps) its running statistics
             return _BottleneckFn.apply(x, self, cfg, *ps)
-        if self.training:
-            with torch.no_grad():
-                return E.bottleneck_fwd(cfg, x, self, True)[0]
-        if _needs_grad(x, *ps):
-            raise RuntimeError("backward through eval-mode (frozen BatchNorm) blocks is not implemented; "
-                               "call .train() or wrap in torch.no_grad()")
         with torch.no_grad():
-            return E.bottleneck_fwd(cfg, x, self, False)[0]
+            return E.bottleneck_fwd(cfg, x, self, self.training)[0]
 
 
 # ------------------------------------------------------------------ head -----
@@ -215,13 +209,34 @@ class ASPP(nn.Module):
 class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, head, cfg, *params):
-        logits, st = E.head_fwd(cfg, x, head, True)
+        logits, st = E.head_fwd(cfg, x, head, head.training, frozen=not head.training)
         ctx.st, ctx.head, ctx.cfg = st, head, cfg
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         dx, grads = E.head_bwd(ctx.cfg, ctx.st, dlogits.contiguous(), ctx.head)
+        ctx.st = None
+        return (dx, None, None, *grads)
+
+
+class _HeadForkFn(torch.autograd.Function):
+    """A branch head at a split point: returns (logits, x) where x goes on into the next backbone section.
+    Backward therefore receives the next section's gradient of x TOGETHER with dlogits and the head's first
+    data-gradient conv adds into it through its epilogue; with two separate consumers autograd would sum the two
+    [N,h,w,C] gradients with a torch elementwise kernel (3 tensor passes) inside the training step."""
+
+    @staticmethod
+    def forward(ctx, x, head, cfg, *params):
+        logits, st = E.head_fwd(cfg, x, head, head.training, frozen=not head.training)
+        ctx.st, ctx.head, ctx.cfg = st, head, cfg
+        return logits, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dlogits, dx_next):
+        if dx_next is not None:
+            dx_next = dx_next.contiguous()
+        dx, grads = E.head_bwd(ctx.cfg, ctx.st, dlogits.contiguous(), ctx.head, dx_init=dx_next)
         ctx.st = None
         return (dx, None, None, *grads)
 
@@ -277,15 +292,19 @@ class DeepLabHead(nn.Sequential):
     def forward(self, x):
         cfg = self.__dict__["cfg"]
         ps = self.param_list()
-        if self.training and _needs_grad(x, *ps):
+        if _needs_grad(x, *ps):        # .eval() + autograd: frozen statistics, no dropout
             return _HeadFn.apply(x, self, cfg, *ps)
-        if self.training:
-            with torch.no_grad():
-                return E.head_fwd(cfg, x, self, True)[0]
-        if _needs_grad(x, *ps):
-            raise RuntimeError("backward through an eval-mode head is not implemented; call .train()")
         with torch.no_grad():
-            return E.head_fwd(cfg, x, self, False)[0]
+            return E.head_fwd(cfg, x, self, self.training)[0]
+
+    def forward_fork(self, x):
+        """-> (logits, x to feed the next backbone section).  Same numbers as ``(self(x), x)``; in a training
+        step the two gradients of x are then summed inside the head's data-gradient kernel (_HeadForkFn)."""
+        cfg = self.__dict__["cfg"]
+        ps = self.param_list()
+        if _needs_grad(x, *ps) and x.requires_grad:
+            return _HeadForkFn.apply(x, self, cfg, *ps)
+        return self(x), x
 
 
 class Section(nn.Sequential):

@@ -7,6 +7,11 @@ import torch
 from . import _lib, engine
 
 
+def _same_layout(g, p):
+    """True when g and p place element [i,j,...] at the same offset (strides of size-1 dims are irrelevant)."""
+    return g.shape == p.shape and all(a == b for a, b, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
+
+
 class SGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
         if lr < 0 or momentum < 0 or weight_decay < 0:
@@ -42,7 +47,12 @@ class SGD(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)
                     first = True
                 g = p.grad
-                if g.stride() != p.stride() and p.numel() > 1:      # kernels index raw memory
+                if not _same_layout(g, p):                          # kernels index raw memory
+                    if self.static_grads:
+                        # arena / HIP-graph mode: the backward kernels keep writing the arena, so a private copy would
+                        # freeze this gradient at its first value (and fall out of the data-parallel buckets)
+                        raise _lib.EesegError(f"gradient of a {tuple(p.shape)} parameter is laid out differently from "
+                                              "the parameter; static (arena) gradients cannot be re-bound")
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
                     g2.copy_(g)
                     p.grad = g = g2

@@ -5,7 +5,8 @@ materialised or copied to the host (the reference moves both maps to numpy and c
 
 scikit-image is not installed in the build image and the reference holds no fixture for these functions, so
 their parity is *unpinned*: the formulas are the published scikit-image ones (see oracle/sim_ref.py).  SSIM
-(:15-39, a windowed statistic of the label IMAGE, not a function of the table) is not provided.
+(:15-37) is a windowed statistic of the label IMAGE, not a function of the table: both exits' label maps are
+produced by the fused upsample+argmax kernel and ``eeseg_ssim_labels`` reduces them on the device.
 
 Every metric takes ``(a, b)`` = two ``[1,C,H,W]`` score tensors, two ``[H,W]`` label maps, or an ``ExitLogits``
 plus two exit indices via ``pair_table`` and returns a python float, like the reference.
@@ -84,6 +85,40 @@ def vi_from_table(t, ignore=()):
     hygx = -(px * xlogx(pxy * inv(px)[:, None]).sum(dim=1)).sum()
     hxgy = -(xlogx(pxy * inv(py)[None, :]).sum(dim=0) * py).sum()
     return float(hygx.item()), float(hxgy.item())
+
+
+def label_map(t, exit_index=None):
+    """[N,H,W] int64 argmax label maps of an ExitLogits exit / a [N,C,H,W] score tensor / label maps."""
+    if isinstance(t, ExitLogits):
+        return K.argmax_confusion(t.lowres[exit_index].detach().contiguous(), t.num_classes, None, *t.size,
+                                  want_pred=True)[1]
+    if t.dim() == 4:
+        lr, C, size = _as_lowres_batch(t)
+        return K.argmax_confusion(lr, C, None, *size, want_pred=True)[1]
+    t = t.squeeze()
+    return (t if t.dim() == 3 else t.unsqueeze(0)).long().contiguous()
+
+
+def _as_lowres_batch(t):
+    N, C, H, W = t.shape
+    lr = torch.zeros((N, H, W, E.CPAD), dtype=torch.float32, device=t.device)
+    lr[..., :C] = t.detach().permute(0, 2, 3, 1)
+    return lr, C, (H, W)
+
+
+class SSIM:
+    """sim_metrics.py:15-37: skimage's structural_similarity (defaults) of the two argmax label maps, with the
+    caller's `data_range`.  Returns a python float for one image (as the reference), a list for a batch."""
+
+    def __init__(self, data_range):
+        self.dr = data_range
+
+    def device_value(self, a, b, exit_a=None, exit_b=None):
+        return K.ssim_labels(label_map(a, exit_a), label_map(b if b is not None else a, exit_b), self.dr)
+
+    def __call__(self, a, b, exit_a=None, exit_b=None):
+        v = self.device_value(a, b, exit_a, exit_b).cpu()
+        return float(v[0]) if v.numel() == 1 else v.tolist()
 
 
 def MSE(a, b, **kw):

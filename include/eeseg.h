@@ -263,6 +263,11 @@ int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target,
  * ee_dnn_op.py:86) are functions of this table, so no label map leaves the device. */
 int eeseg_argmax_pair_hist(const float* logits_a, const float* logits_b, int ldc, int N, int C, int h, int w, int H, int W,
                            int32_t* hist, void* stream);
+/* SSIM of two integer label maps [N,H,W] int64 (sim_metrics.py:15-37: skimage.metrics.structural_similarity with its
+ * defaults - 7x7 uniform window, sample covariance, K1 0.01, K2 0.03, mean over the map cropped by 3 px per side, float64).
+ * ssim_out[N] double, overwritten. */
+int eeseg_ssim_labels(const int64_t* labels_a, const int64_t* labels_b, int N, int H, int W, double data_range,
+                      double* ssim_out, void* stream);
 /* Fused upsample + softmax + normalised entropy (+ s x s max/min block pool) +
  * mean per image (eval_br_ent.py:19-36).  entropy_out[N] fp32; exit_flag[N]
  * int32 = (entropy < tau) stays on device (eval_br_ent.py:60, ee_dnn_op_ne.py:81).

@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE - see ``oracle/__init__.py``.
 
 The reference computes them with scikit-image (sim_metrics.py:41-120: ``mean_squared_error``,
-``normalized_mutual_information``, ``variation_of_information``), which is NOT installed here and has no
+``normalized_mutual_information``, ``variation_of_information``; ``structural_similarity`` at :15-37), which is NOT installed here and has no
 fixture in the reference: **parity unpinned**.  What follows restates the published scikit-image 0.19+
 algorithms on integer label maps:
   * MSE  = mean((a - b)^2) over pixels, float64;
@@ -72,3 +72,25 @@ def vi_pair(a, b, ignore_labels=()):
 
 def vi(a, b, ignore_labels=()):
     return float(np.sum(vi_pair(a, b, ignore_labels)))
+
+
+def ssim(a, b, data_range, win=7, k1=0.01, k2=0.03):
+    """sim_metrics.py:15-37 -> skimage.metrics.structural_similarity(im1, im2, data_range=dr) on integer label maps,
+    restated from the published algorithm (Wang et al. 2004 as implemented by scikit-image: uniform 7x7 window,
+    use_sample_covariance=True, float64, mean over the map cropped by (win-1)//2 per side).  **parity unpinned**
+    (scikit-image absent, no fixture in the reference).  Window means via a summed-area table: in the cropped
+    interior the 7x7 window never touches the border, so the filter's boundary mode does not matter."""
+    a, b = label_maps(a, b)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+
+    def box(x):
+        s = np.zeros((x.shape[0] + 1, x.shape[1] + 1))
+        s[1:, 1:] = x.cumsum(0).cumsum(1)
+        return (s[win:, win:] - s[:-win, win:] - s[win:, :-win] + s[:-win, :-win]) / (win * win)
+
+    ux, uy = box(a), box(b)
+    cov = win * win / (win * win - 1.0)
+    vx, vy, vxy = cov * (box(a * a) - ux * ux), cov * (box(b * b) - uy * uy), cov * (box(a * b) - ux * uy)
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return float(s.mean())

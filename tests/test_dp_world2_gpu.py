@@ -1,0 +1,158 @@
+"""Data-parallel numerics with world size 2 on ONE GPU: two processes (one rank each, both on cuda:0) under a
+gloo process group, device tensors staged through the host by engine.Config.collective.  Unlike the 1-rank RCCL
+rehearsal (every collective = identity) this makes SyncBN's `count * world` statistics, the global CE valid-pixel
+normaliser, the arena bucket average and the exact (all-gather) Lovasz mode produce non-trivial results, which
+must equal ONE process stepping on the whole batch.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG = dict(C=21, B=4, img=97, arch="deeplabv3_resnet50", n=1)
+WATCH = ["base_model.0.1", "base_model.0.5.bn2", "base_model.1.1.bn3", "classifier.0.convs.4.2", "classifier.2",
+         "branches.0.0.project.1"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(loss_name):
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_model_gpu import _inputs, _pair
+    net, _ = _pair(CFG["arch"], CFG["n"], CFG["img"], CFG["C"])
+    net.train()
+    net.fused_outputs = True
+    X, y = _inputs(CFG["B"], CFG["C"], CFG["img"], CFG["img"])
+    # unequal void share per half batch, so the global CE normaliser differs from both local ones
+    y[:2][torch.rand(2, 1, CFG["img"], CFG["img"], generator=torch.Generator().manual_seed(3)) < 0.4] = CFG["C"]
+    if loss_name == "ce":
+        from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+        crit = BrXEntropyLoss(ignore_index=CFG["C"], b_reduction="sum", n_exits=2)
+    else:
+        from ee_semantic_segmentation_amd.branchy_seg_losses import LovaszSoftmax
+        crit = LovaszSoftmax(ignore=CFG["C"], n_branches=1)
+    return net, crit, X, y
+
+
+def _step(net, crit, X, y, reducer=None):
+    """One training step WITHOUT the optimizer update; returns what the comparison needs."""
+    from ee_semantic_segmentation_amd.optim import SGD
+    arena = net.enable_grad_arena()
+    if reducer is not None:
+        reducer = reducer(net)
+    loss = crit(net(X.to(DEV)), y.to(DEV))
+    loss.mean().backward()
+    if reducer is not None:
+        reducer.finish()
+    torch.cuda.synchronize()
+    mods = dict(net.named_modules())
+    out = {"loss": float(loss.item()), "grad": arena.flat.detach().cpu().clone()}
+    for k in WATCH:
+        out[k + ".mean"] = mods[k].running_mean.detach().cpu().clone()
+        out[k + ".var"] = mods[k].running_var.detach().cpu().clone()
+    # and a real SGD step on top (arena gradients -> weights)
+    opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    opt.static_grads = True
+    opt.step()
+    torch.cuda.synchronize()
+    out["w"] = dict(net.named_parameters())["base_model.0.4.conv1.weight"].detach().cpu().clone()
+    return out
+
+
+def _child(rank, port, loss_name, path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from ee_semantic_segmentation_amd.parallel import ArenaReducer
+
+    def staged(t, group):                 # gloo moves host memory: stage the device tensor through it
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+
+    net, crit, X, y = _build(loss_name)
+    net.cfg.sync_bn = True
+    def staged_gather(t, group):
+        h = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(2)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(t.device)
+
+    net.cfg.collective = staged
+    net.cfg.gatherer = staged_gather
+    half = CFG["B"] // 2
+    sl = slice(rank * half, (rank + 1) * half)
+    out = _step(net, crit, X[sl], y[sl], reducer=lambda n: ArenaReducer(n, bucket_bytes=32 << 20))
+    torch.save(out, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss_name", ["ce", "lovasz"])
+def test_two_ranks_equal_one_process_on_the_whole_batch(loss_name):
+    net, crit, X, y = _build(loss_name)
+    whole = _step(net, crit, X, y)
+    del net
+    torch.cuda.empty_cache()
+    port = _free_port()
+    tmp = tempfile.mkdtemp(prefix="eeseg_dp2_")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = []
+    for r in range(2):
+        path = os.path.join(tmp, f"rank{r}.pt")
+        procs.append((path, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", str(r), str(port),
+                                              loss_name, path], env=env, stdout=subprocess.PIPE,
+                                             stderr=subprocess.PIPE, text=True)))
+    outs = []
+    for path, p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, f"rank process failed (rc={p.returncode}):\n{se[-3000:]}"
+        outs.append(torch.load(path, weights_only=True))
+    r0, r1 = outs
+
+    def rel(a, b):
+        return (a.double() - b.double()).abs().max().item() / (b.double().abs().max().item() + 1e-30)
+
+    # the DP average of the two rank losses is the whole-batch loss (global normaliser / joint ranking)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - whole["loss"]) < 2e-5 * abs(whole["loss"]), (r0["loss"], r1["loss"],
+                                                                                                whole["loss"])
+    if loss_name == "ce":
+        assert abs(r0["loss"] - r1["loss"]) > 1e-3 * abs(whole["loss"])      # the shards really differ
+    # SyncBN: both ranks hold the whole batch's statistics
+    for k in WATCH:
+        for s in (".mean", ".var"):
+            assert torch.equal(r0[k + s], r1[k + s]), k + s
+            assert rel(r0[k + s], whole[k + s]) < 1e-4, (k + s, rel(r0[k + s], whole[k + s]))
+    # averaged gradients: identical on both ranks, and the whole-batch gradient up to summation order (the first
+    # step sits below the chaos band of DESIGN.md section 5: quantiles over the arena, not a max over 40 M numbers)
+    assert torch.equal(r0["grad"], r1["grad"])
+    g, gw = r0["grad"].double(), whole["grad"].double()
+    err = (g - gw).abs()
+    scale = gw.abs().max().item()
+    stats = {"max": err.max().item() / scale, "p999": err.kthvalue(int(0.999 * err.numel())).values.item() / scale,
+             "cos": float((g * gw).sum() / (g.norm() * gw.norm()))}
+    print("dp2 gradient agreement", loss_name, json.dumps(stats))
+    assert stats["cos"] > 0.9999 and stats["p999"] < 2e-3 and stats["max"] < 5e-2, stats
+    assert rel(r0["w"], whole["w"]) < 1e-5 and torch.equal(r0["w"], r1["w"])
+
+
+if __name__ == "__main__" and "--child" in sys.argv:
+    sys.path.insert(0, ROOT)
+    i = sys.argv.index("--child")
+    _child(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3], sys.argv[i + 4])

@@ -453,13 +453,58 @@ def test_conv_alternate_pipelines(pipe, dtype):
     """The LDS-DMA staged K loop (EESEG_OPT_CONV_PIPE=0) and the 1-deep register pipeline give
     the same results as the default 2-deep one (padding taps = zero-filled DMA lanes included)."""
     from ee_semantic_segmentation_amd._lib import lib
+    old = lib().eeseg_get_option(1)
     lib().eeseg_set_option(1, pipe)
     try:
         for case in [(2, 13, 11, 64, 128, 3, 1, 1, 1), (1, 17, 17, 128, 256, 3, 1, 12, 12), (3, 17, 13, 128, 64, 1, 1, 0, 1),
                      (2, 15, 14, 64, 128, 3, 2, 1, 1)]:
             test_conv_fwd_dgrad_wgrad(case, dtype)
     finally:
-        lib().eeseg_set_option(1, 2)
+        lib().eeseg_set_option(1, old)
+    assert lib().eeseg_get_option(1) == 3, "the 256-tile kernel is the default conv pipeline"
+
+
+BIG_TILE_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil - multi-tile shapes of the 256 px x 256 cout kernel (bf16, Cout % 256 == 0)
+    (2, 96, 96, 64, 1024, 1, 1, 0, 1),        # 72 pixel tiles x 4 cout tiles = 288 blocks: a full round + K-split tail
+    (2, 33, 33, 128, 256, 3, 1, 12, 12),      # atrous, 9 tiles, tap skipping at the borders
+    (1, 40, 52, 256, 512, 3, 1, 2, 2),        # 3x3 dilated (layer3-like), two cout tiles, ragged last pixel tile
+]
+
+
+@pytest.mark.parametrize("case", BIG_TILE_CASES, ids=[str(c) for c in BIG_TILE_CASES])
+def test_conv_256_tile_kernel_vs_torch(case):
+    """the 256-tile kernel (forward, fused epilogue, data-gradient) and the 256-tile weight-gradient
+    kernel against F.conv2d itself at multi-tile shapes - not against the 128-tile kernel."""
+    from ee_semantic_segmentation_amd._lib import lib
+    assert lib().eeseg_get_option(1) == 3
+    N, H, W, Cin, Cout, k, s, p, d = case
+    dtype = torch.bfloat16
+    x = rnd(dtype, N, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p, dilation=d)
+    gy = rnd(dtype, *y.shape, seed=3)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wf, wb = K.pack_weight(w.detach().to(DEV), dtype)
+    yd, part = K.conv_fwd(xd, wf, s, p, d, want_stats=True)
+    close(nchw(yd), y, tol(dtype), "256-tile conv fwd")
+    ys = yd.float().reshape(-1, Cout)
+    sums = K.reduce_partials(part)
+    close(sums[0], ys.sum(0), 1e-4, "stats sum")
+    close(sums[1], (ys * ys).sum(0), 1e-4, "stats sumsq")
+    sc = torch.rand(Cout, generator=torch.Generator().manual_seed(1)) + 0.5
+    sh = torch.randn(Cout, generator=torch.Generator().manual_seed(2))
+    res = rnd(dtype, *y.shape, seed=4)
+    y2, _ = K.conv_fwd(xd, wf, s, p, d, scale=sc.to(DEV), shift=sh.to(DEV), residual=nhwc(res).to(DEV, dtype), relu=True)
+    want2 = torch.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    close(nchw(y2), want2, tol(dtype), "256-tile fused epilogue")
+    gyd = nhwc(gy).to(DEV, dtype)
+    if Cin % 256 == 0:                     # the data-gradient is a conv with Cout' = Cin: 256-tile eligible
+        dx = K.conv_dgrad(gyd, wb, (H, W), s, p, d)
+        close(nchw(dx), x.grad, tol(dtype), "256-tile conv dgrad")
+    dw = K.conv_wgrad(xd, gyd, k, k, s, p, d)
+    close(dw.permute(0, 3, 1, 2), w.grad, 4e-3, "conv wgrad")
 
 
 def test_bn_reduce_finalize_fused_equals_two_step():
@@ -648,6 +693,50 @@ def test_similarity_gates_from_pair_histogram():
     # identities: identical maps -> MSE 0, VI 0, NMI 2
     kw = dict(exit_a=0, exit_b=0)
     assert M.MSE(el, None, **kw) == 0.0 and abs(M.VI()(el, None, **kw)) < 1e-12 and abs(M.NMI(el, None, **kw) - 2.0) < 1e-9
+
+
+def test_ssim_gate_matches_oracle():
+    """sim_metrics.SSIM (sim_metrics.py:15-37) on the device vs the numpy restatement of skimage's
+    structural_similarity defaults (oracle/sim_ref.py: parity unpinned, scikit-image is not installed) + identities."""
+    from ee_semantic_segmentation_amd import sim_metrics as M
+    from ee_semantic_segmentation_amd.eval_br_sim import br_evaluator
+    from ee_semantic_segmentation_amd.from_deepv3_new import ExitLogits
+    from oracle import sim_ref as R
+    gen = torch.Generator().manual_seed(12)
+    C, H, W = 21, 70, 101
+    los = []
+    for k in range(2):
+        lo = torch.zeros(2, 9, 13, 32)
+        lo[..., :C] = torch.randn(2, 9, 13, C, generator=gen) * 3
+        los.append(lo)
+    los.append(los[0] + 0.5 * los[1])
+    el = ExitLogits([l.to(DEV) for l in los], C, (H, W))
+    full = el.stack().cpu().numpy()              # [E,2,C,H,W]
+    f = M.SSIM(C - 1)
+    for ea, eb in ((0, 1), (0, 2), (2, 1)):
+        got = f.device_value(el, el, ea, eb).cpu().numpy()
+        for b in range(2):
+            want = R.ssim(full[ea][b:b + 1], full[eb][b:b + 1], C - 1)
+            assert abs(got[b] - want) < 1e-12, (ea, eb, b, got[b], want)
+        # score-tensor and label-map entry points (what the reference passes) agree
+        ta, tb = torch.from_numpy(full[ea][:1]).to(DEV), torch.from_numpy(full[eb][:1]).to(DEV)
+        la, lb = R.label_maps(full[ea][:1], full[eb][:1])
+        assert abs(f(ta, tb) - got[0]) < 1e-15
+        assert abs(f(torch.from_numpy(la).to(DEV), torch.from_numpy(lb).to(DEV)) - got[0]) < 1e-15
+    assert abs(f.device_value(el, el, 1, 1).cpu().numpy() - 1.0).max() < 1e-15     # identical maps -> 1
+    small = torch.randint(0, C, (1, 7, 7), generator=gen).to(DEV)                   # exactly one window
+    assert abs(float(K.ssim_labels(small, small, C - 1)[0]) - 1.0) < 1e-15
+    # the evaluator accepts metric='ssim' (eval_br_sim.py:20-21)
+
+    class Net(torch.nn.Module):
+        n_branches, num_classes = 2, C
+
+        def forward_lowres(self, X):
+            return el.lowres
+
+    y = torch.randint(0, C, (2, 1, H, W), generator=gen)
+    res = br_evaluator(Net(), 3, C, [(torch.zeros(2, 3, H, W), y)], DEV, "ssim", 0.2)
+    assert res["out_gl"] == 2 and res["b2_count"] + res["count_out"] == 2
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])

@@ -364,3 +364,87 @@ def test_my_branch_head_strict_and_in_network(bottleneck):
         assert pre.weight.grad.data_ptr() >= net.cfg.arena.flat.data_ptr()     # lives in the arena
     else:
         assert pre is None
+
+
+def test_sgd_trajectory_vs_oracle_frozen_statistics():
+    """SURVEY 8(c) pin for a8/a9/a13: the reference's step `loss = criterion(net(X), y); loss.mean().backward();
+    optimizer.step()` (train_funcs.py:22-27) with the param groups of deepv3_funcs.py:74-99, four steps, HIP fp32 vs
+    the CPU oracle, loss of every step within 1e-4 relative.  BatchNorm runs on its running statistics (network in
+    .eval(), autograd on): without batch statistics over tiny maps the trajectory is well conditioned, so this is a
+    strict whole-network check of forward, backward (incl. dgamma/dbeta) and the fused SGD step together."""
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    from ee_semantic_segmentation_amd.optim import SGD
+    from oracle import losses_ref
+    C, B, img, n, steps = 21, 4, 97, 1, 4
+    net, ref = _pair("deeplabv3_resnet50", n, img)
+    X, y = _inputs(B, C, img, img)
+    # calibrate the running statistics on this batch (momentum 1 -> running = batch statistics), then freeze
+    ref.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():
+        ref(X)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.1
+    net.load_state_dict(ref.state_dict())
+    ref.eval()
+    net.eval()
+    lr = 0.01
+
+    def groups(m):
+        return [{"params": m.base_model.parameters(), "lr": lr}, {"params": m.branches.parameters(), "lr": lr},
+                {"params": m.classifier.parameters(), "lr": 1.1 * lr}]
+
+    opt_ref = torch.optim.SGD(groups(ref), lr=lr, momentum=0.9, weight_decay=5e-4)
+    opt = SGD(groups(net), lr=lr, momentum=0.9, weight_decay=5e-4)
+    crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=n + 1)
+    Xd, yd = X.to(DEV), y.to(DEV)
+    want, got = [], []
+    for _ in range(steps):
+        l = losses_ref.br_xentropy(ref(X), y, ignore_index=C, b_reduction="sum", n_exits=n + 1)
+        opt_ref.zero_grad()
+        l.mean().backward()
+        opt_ref.step()
+        want.append(l.item())
+        lh = crit(net(Xd), yd)
+        opt.zero_grad()
+        lh.mean().backward()
+        opt.step()
+        got.append(lh.item())
+    want, got = np.array(want), np.array(got)
+    assert np.all(np.abs(got - want) <= 1e-4 * np.abs(want)), (want.tolist(), got.tolist())
+    assert want[-1] < want[0]
+    rp = dict(ref.named_parameters())
+    for name, p in net.named_parameters():          # weights after four updates, every parameter
+        assert _rel(p, rp[name]) < 1e-4, (name, _rel(p, rp[name]))
+    rb = dict(ref.named_buffers())
+    for name, b in net.state_dict().items():        # frozen statistics stayed frozen
+        if name.endswith("running_var") or name.endswith("running_mean"):
+            assert torch.equal(b.cpu(), rb[name]), name
+
+
+def test_whole_network_gradients_strict_frozen_statistics():
+    """a STRICT whole-network gradient check on a well-conditioned configuration - every
+    parameter's gradient within 2e-3 of its scale vs the oracle, BatchNorm on frozen (calibrated) statistics."""
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    from oracle import losses_ref
+    C, B, img, n = 21, 2, 97, 2
+    net, ref = _pair("deeplabv3_resnet50", n, img)
+    X, y = _inputs(B, C, img, img)
+    ref.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    with torch.no_grad():
+        ref(X)
+    net.load_state_dict(ref.state_dict())
+    ref.eval()
+    net.eval()
+    losses_ref.br_xentropy(ref(X), y, ignore_index=C, b_reduction="sum", n_exits=n + 1).mean().backward()
+    out = net(X.to(DEV))
+    BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=n + 1)(out, y.to(DEV)).mean().backward()
+    rp = dict(ref.named_parameters())
+    worst = max((_rel(p.grad, rp[name].grad), name) for name, p in net.named_parameters())
+    assert worst[0] < 2e-3, worst

@@ -128,3 +128,25 @@ def test_region_and_focal_losses_oracle_matches_reference_vectors(golden_dir, k)
             got = np.zeros_like(y.numpy())
         wg = g[f"{name}{k}_grad"]
         assert np.abs(got - wg).max() <= 1e-5 * max(1e-6, np.abs(wg).max()) + 1e-9, name
+
+
+def test_ssim_oracle_against_direct_window_loops():
+    """oracle.sim_ref.ssim (summed-area-table form) vs the definition written out with explicit 7x7 window loops
+    (skimage.metrics.structural_similarity defaults; parity unpinned: scikit-image is absent)."""
+    import numpy as np
+    from oracle import sim_ref as R
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 21, (13, 17))
+    b = np.where(rng.random((13, 17)) < 0.7, a, rng.integers(0, 21, (13, 17)))
+    dr, win = 20.0, 7
+    c1, c2 = (0.01 * dr) ** 2, (0.03 * dr) ** 2
+    vals = []
+    for y in range(13 - win + 1):
+        for x in range(17 - win + 1):
+            wa, wb = a[y:y + win, x:x + win].astype(np.float64), b[y:y + win, x:x + win].astype(np.float64)
+            ux, uy = wa.mean(), wb.mean()
+            vx, vy = wa.var(ddof=1), wb.var(ddof=1)
+            vxy = ((wa - ux) * (wb - uy)).sum() / (win * win - 1)
+            vals.append((2 * ux * uy + c1) * (2 * vxy + c2) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
+    assert abs(R.ssim(a, b, dr) - float(np.mean(vals))) < 1e-12
+    assert abs(R.ssim(a, a, dr) - 1.0) < 1e-15

@@ -119,3 +119,82 @@ def test_arena_reducer_averages_buckets_and_switches_the_cu_plan():
     for _, seen, _, got in res:
         assert seen == [240, 240]
         assert torch.allclose(torch.tensor(got), want, atol=1e-6)
+
+
+def _algebra_worker(rank, world, port, q):
+    """SyncBN statistics and the global CE normaliser through the SAME host functions the HIP path calls
+    (engine.sync_bn_sums / engine.global_mean_normaliser / Config.all_reduce), on CPU tensors over gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ee_semantic_segmentation_amd import engine as E
+        sub = dist.new_group([0, 1])                     # a sub-group object, not the default group
+        cfg = E.Config()
+        cfg.sync_bn, cfg.group = True, sub
+        assert cfg.dp_active() and cfg.sync_active() and cfg.world() == world and cfg.dp_world() == world
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(6, 5, 7, 7, generator=g) * 2 + 0.5         # whole batch [B,C,H,W]; this rank's shard: 3 images
+        xs = x[rank * 3:(rank + 1) * 3].double()
+        sums = torch.stack([xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3))])
+        sums, count = E.sync_bn_sums(cfg, sums, xs.numel() // 5)
+        mean = sums[0] / count
+        var = sums[1] / count - mean * mean
+        ref_mean, ref_var = x.double().mean((0, 2, 3)), x.double().var((0, 2, 3), unbiased=False)
+        # CE: per-exit (loss sum, valid count) of the shard -> normaliser; the DP average of the rank losses must be
+        # the whole-batch mean loss (oracle = torch cross_entropy with ignore_index on the whole batch)
+        C = 4
+        logits = torch.randn(2, 6, C, 9, 9, generator=g)                       # [E,B,C,H,W]
+        tgt = torch.randint(0, C + 1, (6, 9, 9), generator=g)
+        tgt[:3][torch.rand(3, 9, 9, generator=g) < 0.5] = C                 # unequal void share per shard
+        sl = slice(rank * 3, (rank + 1) * 3)
+        loss_sum = torch.stack([torch.nn.functional.cross_entropy(logits[e, sl], tgt[sl], ignore_index=C,
+                                                                  reduction="sum") for e in range(2)]).double()
+        cnt = torch.full((2,), float((tgt[sl] != C).sum()), dtype=torch.float64)
+        mine = loss_sum / E.global_mean_normaliser(cfg, cnt)
+        avg = mine.clone()
+        dist.all_reduce(avg, group=sub)
+        avg /= world
+        want = torch.stack([torch.nn.functional.cross_entropy(logits[e], tgt, ignore_index=C) for e in range(2)])
+        q.put((rank, (mean - ref_mean).abs().max().item(), (var - ref_var).abs().max().item(),
+               (avg - want.double()).abs().max().item(), count))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_statistics_and_ce_normaliser_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_algebra_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, emean, evar, eloss, count in res:
+        assert count == 6 * 49
+        assert emean < 1e-12 and evar < 1e-11 and eloss < 1e-6, (emean, evar, eloss)
+
+
+def test_grad_arena_views_have_the_parameter_layout():
+    """every p.grad must be a view INTO the arena with exactly p's strides, or the fused SGD step
+    re-binds it to a private copy that the backward kernels never refresh (torch leaves the strides of a
+    [Co,Ci,1,1] channels_last weight at (Ci,1,1,1), unlike a permuted KRSC view)."""
+    from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
+    from ee_semantic_segmentation_amd.optim import _same_layout
+    net = branchyDeepv3(None, "deeplabv3_resnet50", 1, 65, count_branches=False,
+                        branch_params=dict(atrous_rates=[2, 4], nout_channels=128, bottleneck=64))
+    arena = net.enable_grad_arena()
+    lo, hi = arena.flat.data_ptr(), arena.flat.data_ptr() + arena.flat.numel() * 4
+    n1x1 = 0
+    for name, p in net.named_parameters():
+        assert p.grad is not None and lo <= p.grad.data_ptr() < hi, name
+        assert _same_layout(p.grad, p), (name, p.grad.stride(), p.stride())
+        if p.dim() == 4 and p.shape[2] == 1:
+            n1x1 += 1
+            kv = arena.kernel_view[p]
+            kv.copy_(torch.arange(kv.numel(), dtype=torch.float32).view(kv.shape))
+            assert torch.equal(p.grad, kv[:p.shape[0]].permute(0, 3, 1, 2)), name     # same bytes, same element order
+    assert n1x1 >= 40
