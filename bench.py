@@ -173,9 +173,14 @@ def kernel_events(run, nsteps):
 
 def roofline(prof, prof_steps, dtype, workload_key):
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    fam, k3 = {}, [0.0, 0.0, 0]
+    fam, k3, shapes = {}, [0.0, 0.0, 0], {}
     for name, flops, e0, e1, nbytes, tag in prof:
         sec = e0.elapsed_time(e1) * 1e-3
+        sh = shapes.setdefault(tag, [0.0, 0.0, 0, 0.0])
+        sh[0] += flops
+        sh[1] += sec
+        sh[2] += 1
+        sh[3] += nbytes
         f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
         f[0] += flops
         f[1] += sec
@@ -202,7 +207,15 @@ def roofline(prof, prof_steps, dtype, workload_key):
                           "tflops": k3[0] / max(k3[1], 1e-12) / 1e12, "frac": k3[0] / max(k3[1], 1e-12) / 1e12 / peak,
                           "ms_per_step": k3[1] / prof_steps * 1e3, "launches_per_step": k3[2] / prof_steps},
             "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / prof_steps * 1e3,
-                             "launches_per_step": v[2] / prof_steps} for k, v in fam.items()}}
+                             "launches_per_step": v[2] / prof_steps} for k, v in fam.items()},
+            # per layer shape: measured time against that layer's own roofline max(flops / MFMA peak, algorithmic
+            # bytes / HBM peak) - most 1x1 layers sit below the bf16 ridge and are HBM-bound
+            "by_shape": {k: {"calls_per_step": v[2] / prof_steps, "us_per_call": v[1] / v[2] * 1e6,
+                             "ms_per_step": v[1] / prof_steps * 1e3, "tflops": v[0] / v[1] / 1e12,
+                             "roofline_us": max(v[0] / v[2] / (peak * 1e12), v[3] / v[2] / (PEAK_HBM_GBS * 1e9)) * 1e6,
+                             "bound": "mfma" if v[0] / (peak * 1e12) > v[3] / (PEAK_HBM_GBS * 1e9) else "hbm",
+                             "frac_of_roofline": max(v[0] / (peak * 1e12), v[3] / (PEAK_HBM_GBS * 1e9)) / v[1]}
+                         for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:24]}}
 
 
 def main():
