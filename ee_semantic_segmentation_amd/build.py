@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libeeseg.so")
 STAMP = os.path.join(HERE, ".libeeseg.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wno-unused-result", "-I/opt/rocm/include"]
+         "-Wno-unused-result", "-I/opt/rocm/include"] + os.environ.get("EESEG_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -1050,6 +1050,256 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1, no padding) bf16 convolution for the layers that sit BELOW the bf16 ridge
+// (ResNet bottleneck 1x1s at 65x65: K = 256..1024 - HBM-bound).  The 256x256 kernel above runs
+// one 160-KiB block per CU, so nothing overlaps a tile's epilogue (accumulators -> LDS -> 16-byte row
+// stores, ~4 us) and its first loads: with 4..16 K tiles per tile that fixed cost is half the run time.
+// Here a tile is 128 pixels x 256 couts on 4 waves (64 couts x 128 pixels per wave: the same per-wave
+// shape, so the same 24 B/clk of LDS fragment reads per MFMA-bound wave) and a block needs 74 KiB of
+// LDS and <= 256 VGPRs -> TWO blocks per CU: while one streams its output, the other owns the MFMA pipes
+// and keeps loads in flight.  K tile = 32 channels (64-byte LDS rows), three stages of LDS-DMA
+// (buffer_load ... lds) in flight across one raw barrier per K tile; XOR swizzle on the SOURCE chunk
+// (chunk ^ ((row >> 2) & 3): conflict-free ds_read_b128 for a 64-byte row pitch, MI355X_MICROARCH.md LDS).
+constexpr int PW_BM = 128, PW_BN = 256;
+constexpr int PW_ROW = 64;                                   // bytes of K per LDS row (32 bf16 channels)
+constexpr int PW_XS = PW_BM * PW_ROW, PW_WS = PW_BN * PW_ROW;
+constexpr int PW_STAGE = PW_XS + PW_WS;                      // 24 KiB
+constexpr int PW_NST = 3;
+constexpr int PW_SROW = PW_BN * 2 + 16;                      // staged output row (bf16) + pad
+constexpr int PW_EPI = PW_BM * PW_SROW + 4 * 2 * PW_BN * 4;  // staging + [4 waves][2][256] stats
+constexpr int PW_LDS = (PW_EPI > PW_NST * PW_STAGE ? PW_EPI : PW_NST * PW_STAGE) + 16;
+
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
+    typedef bf16_t T;
+    typedef Mma<T>::Frag Frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __shared__ __attribute__((aligned(16))) char smem[PW_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;    // cout tiles fastest: the 1..8 blocks that share a pixel tile are neighbours
+    const int m0 = mt * PW_BM, n0 = nt * PW_BN;
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+#ifdef EESEG_PW_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) per block into the conv workspace, nothing reads them
+#define PW_STAMP(i) if (tid == 0 && p.slabs) reinterpret_cast<unsigned long long*>(p.slabs)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PW_STAMP(i)
+#endif
+    PW_STAMP(0);
+
+    f32x16 acc[2][4];
+    {
+        // DMA roles: one wave instruction = 16 rows x 64 B (lane -> row lane>>2, chunk slot lane&3).  The first two K
+        // tiles are requested before anything else happens in the block (their latency is the longest thing in a tile
+        // of 4..40 K tiles), the accumulators are produced by the first K tile's MFMAs (C = 0) instead of 128 moves.
+        const int lrow = lane >> 2, slot = lane & 3;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
+        uint32_t voffX[2], voffW[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wave * 2 + q) * 16 + lrow;
+            const int m = m0 + r;
+            voffX[q] = m < p.M ? (uint32_t)(m * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4)) : EESEG_OOB;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = (wave * 4 + q) * 16 + lrow;
+            voffW[q] = (uint32_t)((n0 + r) * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4));
+        }
+        const int nk = p.Cin / 32;
+        auto issue = [&](int kt, int st) {
+            const bool live = kt < nk;                       // past the end: out-of-range loads (zeros, no traffic) keep vmcnt uniform
+            const int soff = kt * PW_ROW;
+            char* sx = smem + st * PW_STAGE;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16,
+                                                         (int)(live ? voffX[q] : EESEG_OOB), soff, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave * 4 + q) * 1024), 16,
+                                                         (int)(live ? voffW[q] : EESEG_OOB), soff, 0, 0);
+        };
+        issue(0, 0);
+        issue(1, 1);
+        PW_STAMP(1);
+        auto ktile = [&](int t, int st, int st2, bool first) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K tile t landed (this wave's pieces)
+            BIG_BARRIER();                                     // ... everybody's; and stage (t-1)%3 has no reader left
+            issue(t + 2, st2);
+            const char* sb = smem + st * PW_STAGE;
+            Frag a[2][2], b[4][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* r = sb + PW_XS + (wave * 64 + i * 32 + fr) * PW_ROW;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* r = sb + (j * 32 + fr) * PW_ROW;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b[j][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (first && ks == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ks], b[j][ks], z, 0, 0, 0);
+                        } else {
+                            Mma<T>::run(a[i][ks], b[j][ks], acc[i][j]);
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        ktile(0, 0, 2, true);
+        int st = 1, st2 = 0;
+        for (int t = 1; t < nk; ++t) {
+            ktile(t, st, st2, false);
+            st = st == PW_NST - 1 ? 0 : st + 1;
+            st2 = st2 == PW_NST - 1 ? 0 : st2 + 1;
+        }
+        PW_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing out-of-range DMAs still write (zeros) into LDS
+        __syncthreads();
+    }
+    PW_STAMP(3);
+
+    // ---- epilogue 1: acc -> (scale, shift) -> LDS staging [pixel][cout] (as the 256-tile kernel) ----
+    char* stage = smem;
+    float* sRed = reinterpret_cast<float*>(smem + PW_BM * PW_SROW);   // [4 waves][2][256]
+    const bool affine = p.scale != nullptr || p.shift != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wave * 64 + i * 32 + 8 * g + 4 * fh;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (affine) {
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n0 + cl);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n0 + cl);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int px = j * 32 + fr;
+                T v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(affine ? acc[i][j][4 * g + e] * sc[e] + sh[e] : acc[i][j][4 * g + e]);
+                *reinterpret_cast<bf16x4*>(stage + px * PW_SROW + ((cl * 2) ^ (((px >> 3) & 1) << 3))) = bf16x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+    __syncthreads();
+    PW_STAMP(4);
+
+    // ---- epilogue 2: row-major read back, residual / ReLU, coalesced 16-byte stores, BN partial sums ----
+    const int c = tid & 31, r0 = tid >> 5;                     // 8 rows per pass, 16 passes
+    const int cg = n0 + c * 8;
+    T* yout = reinterpret_cast<T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const bool post = res != nullptr || p.relu;
+    i32x4 rq[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = r0 + 8 * it;
+        const i32x4 q = *reinterpret_cast<const i32x4*>(stage + row * PW_SROW + c * 16);
+        rq[it] = ((row >> 3) & 1) ? i32x4{q[2], q[3], q[0], q[1]} : q;
+    }
+    if (post) {
+        i32x4 rr[16];
+        if (res != nullptr) {                                  // all residual loads in flight before the first use
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int m = m0 + r0 + 8 * it;
+                rr[it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            union { i32x4 q; T e[8]; } u, ur;
+            u.q = rq[it];
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = to_f32(u.e[e]);
+            if (res != nullptr) {
+                ur.q = rr[it];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(ur.e[e])));
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u.e[e] = from_f32<T>(f[e]);
+            rq[it] = u.q;
+        }
+    }
+    {
+        T* yrow = yout + (size_t)(m0 + r0) * p.ldy + cg;
+        const size_t ystep = (size_t)8 * p.ldy;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (m0 + r0 + 8 * it < p.M) *reinterpret_cast<i32x4*>(yrow) = rq[it];
+            yrow += ystep;
+        }
+    }
+    PW_STAMP(5);
+    if (p.stats) {                                             // of the values as stored (bf16)
+        f32x2 a1[4], a2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (m0 + r0 + 8 * it < p.M) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned w = (unsigned)rq[it][k];
+                    const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                    a1[k] += f;
+                    a2[k] += f * f;
+                }
+            }
+        }
+        float s1[8], s2[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s1[2 * k] = a1[k][0]; s1[2 * k + 1] = a1[k][1];
+            s2[2 * k] = a2[k][0]; s2[2 * k + 1] = a2[k][1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 32);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sRed[(wave * 2 + 0) * PW_BN + lane * 8 + e] = s1[e];
+                sRed[(wave * 2 + 1) * PW_BN + lane * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        const int col = tid;                                   // 256 threads = 256 couts, both sums; one stat row per 128 pixels
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const float t = sRed[(0 * 2 + which) * PW_BN + col] + sRed[(1 * 2 + which) * PW_BN + col] +
+                            sRed[(2 * 2 + which) * PW_BN + col] + sRed[(3 * 2 + which) * PW_BN + col];
+            p.stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = t;
+        }
+    }
+    PW_STAMP(6);
+}
+
+int g_conv_pw_max_k = 1280;   // EESEG_OPT_CONV_PW_MAX_K: pointwise bf16 layers with Cin <= this use conv_pw_kernel (0 = never)
+
 int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K range of a split tail tile holds at least
 int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
@@ -1172,6 +1422,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_linear = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_PW_MAX_K && value >= 0 && value <= 65536) {
+        g_conv_pw_max_k = value;
+        return EESEG_OK;
+    }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);
     return EESEG_ERR_ARG;
 }
@@ -1190,6 +1444,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_BN_ROWS: return g_bn_rows;
         case EESEG_OPT_COLREDUCE_BLOCKS: return g_colreduce_blocks;
         case EESEG_OPT_CONV_SPLIT_MIN_K: return g_conv_big_split_min_k;
+        case EESEG_OPT_CONV_PW_MAX_K: return g_conv_pw_max_k;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1247,6 +1502,19 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     if (g_conv_pipe == 3 && a->dtype == EESEG_BF16 && a->sdiv == 1 && a->Cout % BIGT == 0 && p.vec_ok && affine_ok) {
         p.pointwise = a->R * a->S == 1 && a->smul == 1 && a->off_h == 0 && a->off_w == 0 && a->Hin == a->Hout &&
                       a->Win == a->Wout;
+        // HBM-bound 1x1 layers whose traffic is mostly OUTPUT (expanding convs, data-gradients that add into a residual):
+        // two 128x256 blocks per CU, so one block's epilogue runs beside the other's K loop (measured at 32 x 65 x 65:
+        // 256->1024 150 -> 133 us, with a residual 230 -> 145 us, 512->2048 410 -> 370 us; contracting layers such as
+        // 1024->256 stay on the 256-tile kernel: 101 vs 106 us, their K loop dominates and the bigger tile re-reads W less)
+        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 && (a->Cout >= 2 * a->Cin || a->residual)) {
+            p.n_tiles = a->Cout / PW_BN;
+#ifdef EESEG_PW_STAMPS
+            p.slabs = reinterpret_cast<float*>(a->workspace);
+#endif
+            hipLaunchKernelGGL(conv_pw_kernel, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(256), 0, st, p);
+            EESEG_LAUNCH_CHECK();
+            return EESEG_OK;
+        }
         p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
         return launch_big(p, M, st, a->workspace, a->workspace_bytes);
     }

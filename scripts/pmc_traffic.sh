@@ -5,7 +5,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events > $out/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-secondary --no-kernel-events > $out/$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<PY
@@ -45,7 +45,7 @@ if calls:
         "write_bytes_per_launch": sum(out[k]["write_bytes_per_launch"] * out[k]["launches"] for k in bigs) / calls,
         "hbm_bytes_per_launch": sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches"] for k in bigs) / calls}
 json.dump(out, open("$out/traffic_raw.json", "w"), indent=1)
-json.dump({"workload_key": "resnet50-2-513-16-bf16",
+json.dump({"workload_key": "resnet101-3-513-32-bf16",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over one eager bench step; "
                      "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of wide coalesced reads); "
                      "counts traffic beyond L2 (Infinity-Cache hits included)",

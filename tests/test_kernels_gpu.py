@@ -587,6 +587,66 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
     close(outs["split"][1], ref[1], 2e-3, "split-K BN partial sums")
 
 
+PW_CASES = [
+    # N, H, W, Cin, Cout - pointwise layers of the two-blocks-per-CU 128x256 kernel (conv_pw_kernel: Cin <= 1280)
+    (2, 65, 65, 256, 1024),       # bottleneck conv3: 67 pixel tiles (ragged last one) x 4 cout tiles
+    (3, 33, 31, 1024, 256),       # bottleneck conv1: 32 K tiles (contracting: only its residual forms go to the kernel)
+    (1, 9, 11, 64, 256),          # fewer pixels than one tile, two K tiles (the pipeline prologue covers the whole K loop)
+    (2, 40, 52, 1280, 256),       # ASPP projection: 40 K tiles
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[str(c) for c in PW_CASES])
+def test_conv_pointwise_kernel_vs_torch(case):
+    """conv_pw_kernel (1x1, stride 1, bf16, Cout % 256 == 0, Cin <= EESEG_OPT_CONV_PW_MAX_K) against F.conv2d:
+    plain forward + BN partial sums, fused scale/shift/residual/ReLU epilogue, output into a channel slice of a wider
+    buffer (ASPP concat), data-gradient with in-place accumulation, and the same calls on the 256-tile kernel
+    (EESEG_OPT_CONV_PW_MAX_K = 0) as a cross-check of the dispatch."""
+    from ee_semantic_segmentation_amd._lib import lib
+    assert lib().eeseg_get_option(13) >= 1280
+    N, H, W, Cin, Cout = case
+    dtype = torch.bfloat16
+    x = rnd(dtype, N, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, 1, 1, seed=2, scale=Cin ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w)
+    gy = rnd(dtype, *y.shape, seed=3)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wf, wb = K.pack_weight(w.detach().to(DEV), dtype)
+    sc = torch.rand(Cout, generator=torch.Generator().manual_seed(1)) + 0.5
+    sh = torch.randn(Cout, generator=torch.Generator().manual_seed(2))
+    res = rnd(dtype, *y.shape, seed=4)
+    want2 = torch.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    outs = {}
+    for name, maxk in (("pw", 1280), ("big", 0)):
+        lib().eeseg_set_option(13, maxk)
+        try:
+            assert lib().eeseg_get_option(13) == maxk
+            yd, part = K.conv_fwd(xd, wf, want_stats=True)
+            wide = torch.full((N, H, W, Cout + 256), 7.0, dtype=dtype, device=DEV)
+            K.conv_fwd(xd, wf, out=wide[..., 128:128 + Cout])
+            y2, _ = K.conv_fwd(xd, wf, scale=sc.to(DEV), shift=sh.to(DEV), residual=nhwc(res).to(DEV, dtype), relu=True)
+            outs[name] = (yd, K.reduce_partials(part), wide, y2)
+        finally:
+            lib().eeseg_set_option(13, 1280)
+    for name, (yd, sums, wide, y2) in outs.items():
+        close(nchw(yd), y, tol(dtype), f"{name} fwd")
+        ys = yd.float().reshape(-1, Cout)
+        close(sums[0], ys.sum(0), 1e-4, f"{name} stats sum")
+        close(sums[1], (ys * ys).sum(0), 1e-4, f"{name} stats sumsq")
+        assert torch.equal(wide[..., 128:128 + Cout], yd), f"{name} slice output"
+        assert bool((wide[..., :128] == 7.0).all()) and bool((wide[..., 128 + Cout:] == 7.0).all()), f"{name} wrote outside its slice"
+        close(nchw(y2), want2, tol(dtype), f"{name} fused epilogue")
+    close(outs["pw"][0], outs["big"][0], 8e-3, "pw vs 256-tile kernel")     # (the latter may split K over idle CUs)
+    # data-gradient = pointwise conv with the roles of Cin / Cout swapped (eligible when Cin % 256 == 0)
+    if Cin % 256 == 0:
+        gyd = nhwc(gy).to(DEV, dtype)
+        dx = K.conv_dgrad(gyd, wb, (H, W))
+        close(nchw(dx), x.grad, tol(dtype), "pw dgrad")
+        dx2 = K.conv_dgrad(gyd, wb, (H, W), accumulate_into=dx.clone())
+        close(nchw(dx2), 2 * x.grad, 2 * tol(dtype), "pw dgrad accumulate")
+
+
 @pytest.mark.parametrize("shape", [
     # N, H, W, Cin, Cout, k, stride, pad, dil
     (2, 33, 33, 256, 256, 3, 1, 12, 12),      # atrous: K tiles that are all padding get skipped
