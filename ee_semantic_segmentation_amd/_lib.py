@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
                [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
                                        "smul", "off_h", "off_w", "tstep_h", "tstep_w", "sdiv",
                                        "ldy", "ldres", "relu", "dtype")] + \
-               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("n_active", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -90,6 +90,10 @@ SIGNATURES = {
     "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "eeseg_argmax_pair_hist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "eeseg_entropy_gate_active": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "eeseg_argmax_exit": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "eeseg_exit_select": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "eeseg_gather_images": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "eeseg_ssim_labels": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),

@@ -35,7 +35,12 @@ struct ConvP {
     int n_split_blocks;       // MODE 2: leading blocks that work on K ranges of the tail tiles
     float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
     int pointwise;            // 256x256 kernel: 1x1, stride 1, no padding (source pixel = output pixel)
+    const int* n_active;      // device count of the leading images that are computed at all (NULL = all)
 };
+
+// progressive inference: a block whose first output pixel belongs to an image >= *n_active has nothing to do
+#define EESEG_ACTIVE_EXIT(first_px) \
+    if (p.n_active != nullptr && (long long)(first_px) >= (long long)(*p.n_active) * p.HWout) return
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    EESEG_ACTIVE_EXIT(m0);
     const int taps = p.R * p.S;
 
     // ---- per-thread gather rows (fixed for the whole K loop) -----------------
@@ -505,6 +511,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     const int tile = (split_blk || MODE == 0) ? p.tile_begin + tile_local : tile_local;
     const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
     const int m0 = mt * BIGT, n0 = nt * BIGT;
+    EESEG_ACTIVE_EXIT(m0);
     const int wc = wave & 3, wp = wave >> 2;
     const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
 
@@ -924,6 +931,7 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     const int tile = p.tile_begin + tile_local;
     const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
     const int m0 = mt * BIGT + wp * 128 + j * SL, n0 = nt * BIGT;
+    EESEG_ACTIVE_EXIT(mt * BIGT);            // same decision as the blocks that would have filled this tile's slabs
     const int fr = lane & 31, fh = lane >> 5;
 
     f32x4 acc[2][4];
@@ -1080,6 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;    // cout tiles fastest: the 1..8 blocks that share a pixel tile are neighbours
     const int m0 = mt * PW_BM, n0 = nt * PW_BN;
+    EESEG_ACTIVE_EXIT(m0);
     const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
 #ifdef EESEG_PW_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) per block into the conv workspace, nothing reads them
 #define PW_STAMP(i) if (tid == 0 && p.slabs) reinterpret_cast<unsigned long long*>(p.slabs)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
@@ -1495,6 +1504,8 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
     p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.pointwise = 0;
+    p.n_active = a->n_active;
+    EESEG_CHECK(!a->n_active || !a->stats, EESEG_ERR_ARG, "conv_igemm: n_active is an inference feature (no BN statistics)");
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));
     hipStream_t st = (hipStream_t)stream;

@@ -688,11 +688,12 @@ __global__ __launch_bounds__(256) void argmax_pair_hist_kernel(const float* __re
 
 // ---------------------------------------------------------- entropy gate ----
 __global__ __launch_bounds__(256) void entropy_map_kernel(const float* __restrict__ lr, int ldc, int N, int C, int h,
-                                                          int w, int H, int W, float* emap) {
+                                                          int w, int H, int W, float* emap, const int* n_active) {
     const int lane32 = threadIdx.x & 31;
     const int half = threadIdx.x >> 5;
     const float sh = (float)h / (float)H, sw = (float)w / (float)W;
     const float inv_logc = 1.f / logf((float)C);
+    if (n_active != nullptr && *n_active < N) N = *n_active;      // progressive inference: leading slots only
     const long long total = (long long)N * H * W;
     const bool active = lane32 < C;
     for (long long p = (long long)blockIdx.x * 8 + half; p < total; p += (long long)gridDim.x * 8) {
@@ -715,9 +716,17 @@ __global__ __launch_bounds__(256) void entropy_map_kernel(const float* __restric
 // one block per image: mean of the entropy map, or of its s x s max/min block pool
 // (zero padded to a multiple of s, skimage.block_reduce semantics).
 __global__ __launch_bounds__(1024) void entropy_reduce_kernel(const float* __restrict__ emap, int H, int W, int pool,
-                                                              int s, float tau, float* ent_out, int* flag_out) {
+                                                              int s, float tau, float* ent_out, int* flag_out,
+                                                              const int* n_active, int less_than) {
     __shared__ double sred[16];
     const int n = blockIdx.x;
+    if (n_active != nullptr && n >= *n_active) {            // slot not in flight: no decision
+        if (threadIdx.x == 0) {
+            ent_out[n] = 0.f;
+            if (flag_out) flag_out[n] = 0;
+        }
+        return;
+    }
     const float* e = emap + (size_t)n * H * W;
     double acc = 0.0;
     long long count;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(1024) void entropy_reduce_kernel(const float* __res
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sred[i];
         const float ent = (float)(t / (double)count);
         ent_out[n] = ent;
-        if (flag_out) flag_out[n] = ent < tau ? 1 : 0;
+        if (flag_out) flag_out[n] = ((ent < tau) == (less_than != 0)) ? 1 : 0;
     }
 }
 
@@ -980,6 +989,101 @@ extern "C" int eeseg_ssim_labels(const int64_t* labels_a, const int64_t* labels_
     return EESEG_OK;
 }
 
+// ------------------------------------------------ batched progressive early exit ----
+//   Images still in flight sit in batch slots 0..n_active-1, order[slot] = their index in the caller's
+// batch; both live on the device, so the host enqueues the whole network once and never waits for a gate.
+__global__ __launch_bounds__(256) void argmax_exit_kernel(const float* __restrict__ lr, int ldc, int N, int C, int h, int w,
+                                                          int H, int W, const int* __restrict__ flags,
+                                                          const int* __restrict__ order, const int* n_active,
+                                                          int64_t* pred) {
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int n = blockIdx.y;
+    if (n >= *n_active || (flags != nullptr && flags[n] == 0)) return;
+    int64_t* out = pred + (size_t)order[n] * H * W;
+    const int total = H * W;
+    const bool active = lane32 < C;
+    for (int p = blockIdx.x * 8 + half; p < total; p += gridDim.x * 8) {
+        const int x = p % W, y = p / W;
+        const Src sy = src_index(y, sh, h), sx = src_index(x, sw, w);
+        float z = active ? interp(lr, ldc, h, w, n, sy, sx, lane32) : -INFINITY;
+        int idx = lane32;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {            // first maximum wins (torch.argmax)
+            const float oz = __shfl_xor(z, o);
+            const int oi = __shfl_xor(idx, o);
+            if (oz > z || (oz == z && oi < idx)) { z = oz; idx = oi; }
+        }
+        if (lane32 == 0) out[p] = idx;
+    }
+}
+
+__global__ void exit_select_kernel(const int* __restrict__ flags, int N, int code, int* n_active, int* order, int* src_slot,
+                                   int* exit_idx) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;   // a batch holds tens of images: one lane walks the slots in order
+    int n = *n_active;
+    if (n > N) n = N;
+    int k = 0;
+    for (int s = 0; s < n; ++s) {
+        const int img = order[s];
+        if (flags[s]) {
+            exit_idx[img] = code;
+        } else {
+            order[k] = img;                            // k <= s: never overwrites a slot that is still to be read
+            src_slot[k] = s;
+            ++k;
+        }
+    }
+    *n_active = k;
+}
+
+__global__ __launch_bounds__(256) void gather_images_kernel(const i32x4* __restrict__ x, i32x4* __restrict__ y,
+                                                            const int* __restrict__ src_slot, const int* n_active,
+                                                            long long chunks) {
+    const int k = blockIdx.y;
+    if (k >= *n_active) return;
+    const i32x4* src = x + (size_t)src_slot[k] * chunks;
+    i32x4* dst = y + (size_t)k * chunks;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int eeseg_argmax_exit(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W,
+                                 const int32_t* flags, const int32_t* order, const int32_t* n_active, int64_t* pred_out,
+                                 void* stream) {
+    CHECK_LR("argmax_exit");
+    EESEG_CHECK(order && n_active && pred_out, EESEG_ERR_ARG, "argmax_exit: null pointer");
+    long long blocks = ((long long)H * W + 8 * 16 - 1) / (8 * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(argmax_exit_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc, N, C,
+                       h, w, H, W, (const int*)flags, (const int*)order, (const int*)n_active, pred_out);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_exit_select(const int32_t* flags, int N, int code, int32_t* n_active, int32_t* order, int32_t* src_slot,
+                                 int32_t* exit_idx, void* stream) {
+    EESEG_CHECK(flags && n_active && order && src_slot && exit_idx && N >= 1, EESEG_ERR_ARG, "exit_select: bad argument");
+    hipLaunchKernelGGL(exit_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)flags, N, code,
+                       (int*)n_active, (int*)order, (int*)src_slot, (int*)exit_idx);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_gather_images(const void* x, void* x_out, const int32_t* src_slot, const int32_t* n_active, int N,
+                                   int64_t bytes_per_image, void* stream) {
+    EESEG_CHECK(x && x_out && src_slot && n_active && N >= 1, EESEG_ERR_ARG, "gather_images: bad argument");
+    EESEG_CHECK(bytes_per_image > 0 && bytes_per_image % 16 == 0 && (((uintptr_t)x | (uintptr_t)x_out) & 15) == 0,
+                EESEG_ERR_ARG, "gather_images: images must be 16-byte multiples, 16-byte aligned");
+    const long long chunks = bytes_per_image / 16;
+    long long blocks = (chunks + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(gather_images_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const i32x4*)x,
+                       (i32x4*)x_out, (const int*)src_slot, (const int*)n_active, chunks);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
 extern "C" int64_t eeseg_entropy_gate_workspace(int N, int H, int W) {
     return (int64_t)N * H * W * (int64_t)sizeof(float);
 }
@@ -987,6 +1091,14 @@ extern "C" int64_t eeseg_entropy_gate_workspace(int N, int H, int W) {
 extern "C" int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W, int pool,
                                   int pool_size, float tau, float* entropy_out, int32_t* exit_flag, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
+    return eeseg_entropy_gate_active(logits_lr, ldc, N, C, h, w, H, W, pool, pool_size, tau, 1, nullptr, entropy_out,
+                                     exit_flag, workspace, workspace_bytes, stream);
+}
+
+extern "C" int eeseg_entropy_gate_active(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W,
+                                         int pool, int pool_size, float tau, int less_than, const int32_t* n_active,
+                                         float* entropy_out, int32_t* exit_flag, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
     CHECK_LR("entropy_gate");
     EESEG_CHECK(C >= 2, EESEG_ERR_ARG, "entropy_gate: needs at least 2 classes");
     EESEG_CHECK(entropy_out && workspace && workspace_bytes >= eeseg_entropy_gate_workspace(N, H, W), EESEG_ERR_ARG,
@@ -994,10 +1106,10 @@ extern "C" int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C,
     EESEG_CHECK(pool >= 0 && pool <= 2 && pool_size >= 1, EESEG_ERR_ARG, "entropy_gate: bad pooling mode");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(entropy_map_kernel, dim3(px_grid((long long)N * H * W)), dim3(256), 0, st, logits_lr, ldc, N, C,
-                       h, w, H, W, (float*)workspace);
+                       h, w, H, W, (float*)workspace, (const int*)n_active);
     EESEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(entropy_reduce_kernel, dim3(N), dim3(1024), 0, st, (const float*)workspace, H, W, pool, pool_size,
-                       tau, entropy_out, (int*)exit_flag);
+                       tau, entropy_out, (int*)exit_flag, (const int*)n_active, less_than);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -89,7 +89,14 @@ def train_deepv3(net, num_epochs, kwargs):
         num_workers = kwargs["def_nworkers"](b_size) if "def_nworkers" in kwargs else 0
         p_factor = kwargs["def_prefetch"](b_size) if "def_prefetch" in kwargs and num_workers else None
         scheduler, ret_lr = None, False
-        if use_scheduler:                                        # poly schedule, deepv3_funcs.py:148-153
+        if use_scheduler and kwargs.get("scheduler_patience"):   # deepv3_funcs.py:139-146
+            sp = kwargs["scheduler_patience"]
+            floors = lr * .01 if not kwargs.get("base_lr") else \
+                [kwargs["base_lr"] * .01 for _ in range(len(optimizer.param_groups) - 1)] + [lr * .01]
+            scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=.75, mode="min" if minimize else "max",
+                                                             patience=sp, eps=1e-6, min_lr=floors)
+            ret_lr = True
+        elif use_scheduler:                                      # poly schedule, deepv3_funcs.py:148-153
             if min_lr:
                 w = (min_lr / lr) ** (1 / .9)
                 N_0 = num_epochs * w / (1 - w)
@@ -99,7 +106,7 @@ def train_deepv3(net, num_epochs, kwargs):
                 scheduler = optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda k: (1 - k / num_epochs) ** .9)
             ret_lr = True
         train_loader = utils.data.DataLoader(train_set, batch_size=b_size, shuffle=True, num_workers=num_workers,
-                                             drop_last=True, prefetch_factor=p_factor, pin_memory=True)
+                                             drop_last=False, prefetch_factor=p_factor, pin_memory=True)
         aux = train(net, train_loader, loss, val_iter=val_loader, num_epochs=num_epochs, updater=optimizer,
                     patience=patience, saveat=saveat, start_from=start_from or None, device=device,
                     use_file=use_file, verbose=True, metrics=train_metrics, name=net_id, scheduler=scheduler,

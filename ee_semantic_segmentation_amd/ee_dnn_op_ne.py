@@ -2,9 +2,11 @@
 (ee_dnn_op_ne.py:40-108).  Same ``__call__`` dict contract (``exit``, ``exit_flops``,
 ``edge_flops``, ``n``, ``last``, ``last_flops``); FLOPs come from the analytic conv-MAC
 counter instead of re-tracing pthflops on every call, and the gate is the fused device
-kernel (one 4-byte D2H per gated branch instead of a [C,H,W] probability map).
+kernel whose decision stays on the device (one D2H for all gates at the end of the call
+instead of a [C,H,W] probability map per branch).
 Like the reference this is a FLOP-accounting simulator: the backbone is always finished
-(ee_dnn_op_ne.py:91-101); ``stop_at_exit=True`` really stops."""
+(ee_dnn_op_ne.py:91-101); ``stop_at_exit=True`` really stops through
+``branchyDeepv3.forward_progressive`` - the batched, sync-free form."""
 import torch
 
 from . import kernels as K
@@ -42,43 +44,65 @@ class eval_ee_deeplabv3:
 
     @torch.no_grad()
     def __call__(self, X):
+        """One image [3,H,W] -> the reference's dict.  No gate decision is read back while the network runs: every
+        gate leaves its flag on the device (eeseg_entropy_gate), the masks of all evaluated exits are produced by the
+        fused argmax kernel, and ONE small D2H at the end tells the host which of them is `exit` (SURVEY 8a a11:
+        "branch decisions do not stall the pipeline").  Like the reference the backbone is always finished
+        (ee_dnn_op_ne.py:91-101) and FLOPs are counted up to the exit; `stop_at_exit=True` instead runs
+        branchyDeepv3.forward_progressive, where the sections after the exit cost no GPU work at all."""
         output = dict()
         H, W = X.shape[-2:]
         C = self.model.num_classes
-        main_flops, branch_flops = [], []
-        left = False
+        mode = (2 if self.metric.pool_min else 1) if self.metric.pool else 0
         x = X.unsqueeze(0).to(self.device)
+        # analytic FLOPs of every section / evaluated head (the reference re-traces pthflops per call)
         h, w = H, W
+        sec_flops, head_flops = [], []
         for i in range(self.n):
             f, h, w = section_flops(self.model.base_model[i], h, w)
-            main_flops.append(f)
-            x = self.model.base_model[i](x)
-            if i not in self.ignore and not left:
-                lr = self.model.branches[i](x)
-                branch_flops.append(2 * head_macs(self.model.branches[i], h, w))
-                mode = (2 if self.metric.pool_min else 1) if self.metric.pool else 0
-                ent, _ = K.entropy_gate(lr.contiguous(), C, H, W, self.threshold, mode, self.metric.size[0])
-                t = float(ent[0].item())
-                if (t < self.threshold) == bool(self.less_than):
-                    _, pred = K.argmax_confusion(lr.contiguous(), C, None, H, W, want_pred=True)
-                    output["exit"] = pred[0].cpu()
-                    output["exit_flops"] = sum(branch_flops) + sum(main_flops)
-                    output["edge_flops"] = output["exit_flops"]
-                    output["n"] = i + 1
-                    left = True
-                    if self.stop_at_exit:
-                        return output
-            if not left and i == self.last_br:
-                output["edge_flops"] = sum(branch_flops) + sum(main_flops)
+            sec_flops.append(f)
+            head_flops.append(2 * head_macs(self.model.branches[i], h, w))
         f, h, w = section_flops(self.model.base_model[-1], h, w)
-        main_flops.append(f)
+        sec_flops.append(f)
+        final_flops = 2 * head_macs(self.model.classifier, h, w)
+        gated = [i for i in range(self.n) if i not in self.ignore]
+
+        if self.stop_at_exit:
+            res = self.model.forward_progressive(x, self.threshold, mode, self.metric.size[0], self.less_than, self.ignore)
+            n = int(res["exit"][0].item())                     # the only read-back, after everything is enqueued
+            output["exit"] = res["pred"][0].cpu()
+            output["n"] = n
+            done = [i for i in gated if i < n]                 # heads evaluated before (and at) the exit
+            output["exit_flops"] = sum(head_flops[i] for i in done) + sum(sec_flops[:min(n, self.n + 1)]) + \
+                (final_flops if n == self.n + 1 else 0)
+            output["edge_flops"] = output["exit_flops"] if n <= self.n else \
+                sum(head_flops[i] for i in gated) + sum(sec_flops[:self.last_br + 1])
+            return output
+
+        flags, preds = [], []
+        for i in range(self.n):
+            x = self.model.base_model[i](x)
+            if i in gated:
+                lr = self.model.branches[i](x).contiguous()
+                _, flag = K.entropy_gate(lr, C, H, W, self.threshold, mode, self.metric.size[0], less_than=self.less_than)
+                flags.append(flag)
+                preds.append(K.argmax_confusion(lr, C, None, H, W, want_pred=True)[1])
         x = self.model.base_model[-1](x)
-        main_flops.append(2 * head_macs(self.model.classifier, h, w))
-        lr = self.model.classifier(x)
-        _, pred = K.argmax_confusion(lr.contiguous(), C, None, H, W, want_pred=True)
-        output["last"] = pred[0].cpu()
-        output["last_flops"] = sum(branch_flops) + sum(main_flops)
-        if not left:
+        lr = self.model.classifier(x).contiguous()
+        last = K.argmax_confusion(lr, C, None, H, W, want_pred=True)[1]
+        taken = torch.cat(flags).cpu().tolist() if flags else []          # one D2H for all gates
+        hit = next((j for j, t in enumerate(taken) if t), None)
+        output["last"] = last[0].cpu()
+        all_heads = lambda upto: sum(head_flops[i] for i in gated if i <= upto)
+        output["last_flops"] = (all_heads(gated[hit]) if hit is not None else all_heads(self.n)) + sum(sec_flops) + final_flops
+        if hit is not None:
+            i = gated[hit]
+            output["exit"] = preds[hit][0].cpu()
+            output["exit_flops"] = all_heads(i) + sum(sec_flops[:i + 1])
+            output["edge_flops"] = output["exit_flops"]
+            output["n"] = i + 1
+        else:
+            output["edge_flops"] = all_heads(self.n) + sum(sec_flops[:self.last_br + 1])
             output["exit"] = output["last"]
             output["exit_flops"] = output["last_flops"]
             output["n"] = self.n + 1

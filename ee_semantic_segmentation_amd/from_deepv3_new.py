@@ -308,6 +308,44 @@ class branchyDeepv3(nn.Module):
         outs.append(self.classifier(self.base_model[-1](X)))
         return outs
 
+    @torch.no_grad()
+    def forward_progressive(self, X, tau, pool=0, pool_size=1, less_than=True, ignore=()):
+        """Batched, truly progressive early-exit inference (ee_dnn_op_ne.py:51-108 evaluates one image and
+        always finishes the backbone).  After every non-ignored branch the fused gate decides per image on the device;
+        images that leave get their mask written at their place in the batch, the others are compacted into the leading
+        slots and only those slots are computed from there on (eeseg_conv_args.n_active: conv blocks of later slots
+        return at once).  Nothing is read back between sections: the host enqueues the whole network once.
+
+        Returns {'pred': [B,H,W] int64, 'exit': [B] int32 (the reference's `n`: branch index + 1, n_branches + 1 = the
+        final classifier), 'entropy': [n_branches, B] fp32 gate values by SLOT at the time of the gate} - device tensors."""
+        if self.training:
+            raise RuntimeError("forward_progressive is an inference path: call .eval() first")
+        B, _, H, W = X.shape
+        dev, C = X.device, self.num_classes
+        n_active = torch.full((1,), B, dtype=torch.int32, device=dev)
+        order = torch.arange(B, dtype=torch.int32, device=dev)
+        src_slot = torch.zeros(B, dtype=torch.int32, device=dev)
+        exit_idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        pred = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        ents = torch.zeros((max(self.n_branches, 1), B), dtype=torch.float32, device=dev)
+        x = X
+        with K.active_images(n_active):
+            for i in range(self.n_branches):
+                x = self.base_model[i](x)
+                if i in ignore:
+                    continue
+                lr = self.branches[i](x).contiguous()
+                ent, flag = K.entropy_gate(lr, C, H, W, tau, pool, pool_size, n_active=n_active, less_than=less_than)
+                ents[i] = ent
+                K.argmax_exit(lr, C, H, W, flag, order, n_active, pred)
+                K.exit_select(flag, i + 1, n_active, order, src_slot, exit_idx)
+                x = K.gather_images(x.contiguous(), src_slot, n_active)
+            lr = self.classifier(self.base_model[-1](x)).contiguous()
+            K.argmax_exit(lr, C, H, W, None, order, n_active, pred)
+            K.exit_select(torch.ones(B, dtype=torch.int32, device=dev), self.n_branches + 1, n_active, order, src_slot,
+                          exit_idx)
+        return {"pred": pred, "exit": exit_idx, "entropy": ents}
+
     def forward(self, X):
         size = X.shape[-2:]
         el = ExitLogits(self.forward_lowres(X), self.num_classes, size, self.cfg)

@@ -91,6 +91,26 @@ def _prof_end(ev, family, flops, nbytes=0.0, tag=""):
 _ws_retired = []     # superseded scratch buffers: a captured HIP graph may still hold their addresses
 
 
+# Batched progressive inference: device int32[1] = number of leading batch slots still in flight.  While set, every conv
+# launch carries it (eeseg_conv_args.n_active) and blocks of later slots return at once.
+ACTIVE = None
+
+
+class active_images:
+    def __init__(self, n_active):
+        assert n_active is None or (n_active.dtype == torch.int32 and n_active.numel() == 1 and n_active.is_cuda)
+        self.t = n_active
+
+    def __enter__(self):
+        global ACTIVE
+        self.prev, ACTIVE = ACTIVE, self.t
+        return self.t
+
+    def __exit__(self, *exc):
+        global ACTIVE
+        ACTIVE = self.prev
+
+
 def workspace(nbytes, device):
     """Shared scratch of the reduction / loss / gate kernels.  It only ever grows (geometrically, so the retired
     buffers sum to less than the live one) and a superseded buffer is never freed: the address of the buffer in use at
@@ -150,6 +170,7 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     a.ldy, a.ldres, a.relu, a.dtype = ldy, ldres, int(relu), _dt(x)
     ws = _conv_ws(x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    a.n_active = 0 if (ACTIVE is None or stats is not None) else ACTIVE.data_ptr()
     ev = _prof_begin()
     check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
     if ev is not None:
@@ -583,15 +604,45 @@ def ssim_labels(a, b, data_range):
     return out
 
 
-def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1):
+def entropy_gate(lr, C_, H, W, tau, pool=0, pool_size=1, n_active=None, less_than=True):
+    """-> (entropy [N] fp32, flag [N] int32 = (entropy < tau) == less_than); with `n_active` (device int32[1]) only the
+    leading slots are evaluated (the others get flag 0)."""
     N, h, w, ldc = _lr_dims(lr)
     ent = torch.empty((N,), dtype=torch.float32, device=lr.device)
     flag = torch.empty((N,), dtype=torch.int32, device=lr.device)
     wsb = lib().eeseg_entropy_gate_workspace(N, H, W)
     ws = workspace(wsb, lr.device)
-    check(lib().eeseg_entropy_gate(_p(lr), ldc, N, C_, h, w, H, W, pool, pool_size, float(tau), _p(ent), _p(flag),
-                                   _p(ws), ws.numel(), _stream()), "eeseg_entropy_gate")
+    check(lib().eeseg_entropy_gate_active(_p(lr), ldc, N, C_, h, w, H, W, pool, pool_size, float(tau), int(bool(less_than)),
+                                          _p(n_active), _p(ent), _p(flag), _p(ws), ws.numel(), _stream()),
+          "eeseg_entropy_gate_active")
     return ent, flag
+
+
+def argmax_exit(lr, C_, H, W, flags, order, n_active, pred):
+    """pred[order[slot]] = argmax of the upsampled logits of every active slot that leaves (flags None = all active)."""
+    N, h, w, ldc = _lr_dims(lr)
+    assert pred.dtype == torch.int64 and pred.is_contiguous() and pred.shape[1:] == (H, W) and order.dtype == torch.int32
+    check(lib().eeseg_argmax_exit(_p(lr), ldc, N, C_, h, w, H, W, _p(flags), _p(order), _p(n_active), _p(pred), _stream()),
+          "eeseg_argmax_exit")
+
+
+def exit_select(flags, code, n_active, order, src_slot, exit_idx):
+    """Leaving slots record `code` in exit_idx[image]; the others move to the front of `order` (in place)."""
+    N = flags.numel()
+    for t in (flags, n_active, order, src_slot, exit_idx):
+        assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+    check(lib().eeseg_exit_select(_p(flags), N, int(code), _p(n_active), _p(order), _p(src_slot), _p(exit_idx), _stream()),
+          "eeseg_exit_select")
+
+
+def gather_images(x, src_slot, n_active):
+    """x [N, ...] -> new tensor whose slot k < n_active holds image src_slot[k] (later slots: unspecified)."""
+    assert x.is_contiguous()
+    N = x.shape[0]
+    y = torch.empty_like(x)
+    check(lib().eeseg_gather_images(_p(x), _p(y), _p(src_slot), _p(n_active), N, x[0].numel() * x.element_size(), _stream()),
+          "eeseg_gather_images")
+    return y
 
 
 def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None):

@@ -103,7 +103,12 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
         else:
             cur_val = tracker[follow][-1] if tracker[follow] else 0.0
         if scheduler:
-            scheduler.step()
+            # the reference calls step() without the metric (train_funcs.py:200-201), which ReduceLROnPlateau rejects;
+            # a plateau scheduler gets the value early stopping follows
+            if isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                scheduler.step(cur_val)
+            else:
+                scheduler.step()
             if hasattr(updater, "sync_lr"):
                 updater.sync_lr()
         improved = (best_val > cur_val) if minimize else (best_val < cur_val)

@@ -94,6 +94,10 @@ typedef struct {
     int ldy, ldres, relu, dtype;
     void* workspace;              /* optional scratch (NULL = none): lets the 256x256-tile kernel split the K loop of its */
     int64_t workspace_bytes;      /* last, partly filled round of tiles over the idle CUs; eeseg_conv_workspace() bytes suffice */
+    const int32_t* n_active;      /* optional DEVICE int32 (NULL = all): only the first *n_active images of the batch are computed -
+                                     blocks whose pixels all belong to later images return at once.  Batched progressive
+                                     early-exit inference keeps the images still in flight in the leading slots and
+                                     their count on the device, so no exit decision is ever read back by the host. */
 } eeseg_conv_args;
 int64_t eeseg_conv_workspace(void);
 int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */
@@ -264,6 +268,24 @@ int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target,
  * ee_dnn_op.py:86) are functions of this table, so no label map leaves the device. */
 int eeseg_argmax_pair_hist(const float* logits_a, const float* logits_b, int ldc, int N, int C, int h, int w, int H, int W,
                            int32_t* hist, void* stream);
+/* ---- batched progressive early-exit inference (ee_dnn_op_ne.py:51-108 made real and batched) -------
+ * State on the device: n_active (int32[1]) images are still in flight, occupying batch slots 0..n_active-1;
+ * order[slot] = index of that image in the caller's batch.
+ * eeseg_entropy_gate_active: eeseg_entropy_gate restricted to the active slots; flag = (entropy < tau) == less_than.
+ * eeseg_argmax_exit: upsample + argmax of the slots that leave (flags != NULL: flags[slot] != 0; NULL: all active
+ *   slots) written to pred_out[order[slot]] ([B,H,W] int64).
+ * eeseg_exit_select: for every active slot with flags[slot]: exit_idx[order[slot]] = code; the others are compacted
+ *   to the front: order[k] = their image, src_slot[k] = the slot their features sit in; n_active = their count.
+ * eeseg_gather_images: x_out[k] = x[src_slot[k]] for k < *n_active (bytes_per_image each, 16-byte multiples). */
+int eeseg_entropy_gate_active(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W, int pool,
+                              int pool_size, float tau, int less_than, const int32_t* n_active, float* entropy_out,
+                              int32_t* exit_flag, void* workspace, int64_t workspace_bytes, void* stream);
+int eeseg_argmax_exit(const float* logits_lr, int ldc, int N, int C, int h, int w, int H, int W, const int32_t* flags,
+                      const int32_t* order, const int32_t* n_active, int64_t* pred_out, void* stream);
+int eeseg_exit_select(const int32_t* flags, int N, int code, int32_t* n_active, int32_t* order, int32_t* src_slot,
+                      int32_t* exit_idx, void* stream);
+int eeseg_gather_images(const void* x, void* x_out, const int32_t* src_slot, const int32_t* n_active, int N,
+                        int64_t bytes_per_image, void* stream);
 /* SSIM of two integer label maps [N,H,W] int64 (sim_metrics.py:15-37: skimage.metrics.structural_similarity with its
  * defaults - 7x7 uniform window, sample covariance, K1 0.01, K2 0.03, mean over the map cropped by 3 px per side, float64).
  * ssim_out[N] double, overwritten. */

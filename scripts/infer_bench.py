@@ -1,7 +1,11 @@
-"""Inference-only early-exit benchmark (BASELINE.json configs[3] shape): R101, 4 exits, 1024x2048, B=1, bf16,
-fused entropy gate on every branch + argmax of the chosen exit; all exits computed (like eval_br_ent.py)."""
-import os, sys, time
+"""Inference-only early-exit benchmark (BASELINE.json configs[3]: R101, 4 exits, 1024x2048, entropy-gated, bf16):
+  all:          every exit computed + 3 fused gates + 4 fused argmax masks (eval_br_ent.py's evaluation shape);
+  progressive:  branchyDeepv3.forward_progressive - exits decided on the device, later sections only for the images
+                still in flight (B = 1 and B = 8), exit histogram for thresholds at the quartiles of the gate values.
+usage: python scripts/infer_bench.py [H W]"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from ee_semantic_segmentation_amd import kernels as K
 from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
@@ -10,18 +14,44 @@ C = 19
 torch.manual_seed(0)
 net = branchyDeepv3(None, "deeplabv3_resnet101", 3, 1024, count_branches=False, num_classes=C,
                     compute_dtype=torch.bfloat16).cuda().eval()
-X = torch.randn(1, 3, H, W, device="cuda")
-def step():
+g = torch.Generator().manual_seed(1)
+for m in net.modules():
+    if type(m).__name__ == "BatchNorm2d":
+        m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+        m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+macs = net.macs(H, W)
+
+
+def timed(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
+def all_exits(X):
     with torch.no_grad():
         lrs = net.forward_lowres(X)
-        flags = [K.entropy_gate(lr, C, H, W, 0.5)[1] for lr in lrs[:-1]]
+        gates = [K.entropy_gate(lr, C, H, W, 0.5) for lr in lrs[:-1]]
         preds = [K.argmax_confusion(lr, C, None, H, W, want_pred=True)[1] for lr in lrs]
-    return flags, preds
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 10
-for _ in range(n): step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-macs = net.macs(H, W)
-print(f"R101 4 exits {H}x{W} B=1 bf16 eval (all exits + 3 gates + 4 argmax): {dt*1e3:.2f} ms/img, {1/dt:.1f} img/s, "
-      f"{2*macs/dt/1e12:.0f} TFLOP/s algorithmic ({macs/1e9:.1f} GMAC/img), splits {net.split_names}")
+    return gates, preds
+
+
+res = {"workload": f"DeepLabV3-resnet101 4 exits, {H}x{W}, {C} classes, bf16 inference, splits {net.split_names}",
+       "gmac_per_image_all_exits": macs / 1e9}
+for B in (1, 8):
+    X = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(7)).cuda()
+    X *= torch.linspace(0.3, 2.0, B, device="cuda").view(B, 1, 1, 1)
+    dt, (gates, _) = timed(lambda: all_exits(X))
+    ents = torch.stack([g[0] for g in gates]).cpu().numpy()
+    row = {"all_exits_ms_per_image": dt / B * 1e3, "all_exits_img_per_s": B / dt, "all_exits_tflops": 2 * macs * B / dt / 1e12}
+    for name, q in (("never", None), ("q75", 75), ("q50", 50), ("q25", 25), ("always", 101)):
+        tau = -1.0 if q is None else (2.0 if q > 100 else float(np.percentile(ents, q)))
+        dtp, out = timed(lambda: net.forward_progressive(X, tau))
+        hist = np.bincount(out["exit"].cpu().numpy(), minlength=net.n_branches + 2)[1:].tolist()
+        row[f"progressive_tau_{name}"] = {"tau": tau, "ms_per_image": dtp / B * 1e3, "img_per_s": B / dtp, "exit_histogram": hist}
+    res[f"B={B}"] = row
+print(json.dumps(res, indent=1))

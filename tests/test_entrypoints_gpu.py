@@ -91,7 +91,7 @@ def test_similarity_gated_evaluator_and_progressive_inference():
     keys = {"b1_mIoU", "b1_count", "b2_mIoU", "b2_count", "b3_mIoU", "b3_count", "mIoU_out", "count_out", "mIoU_gl",
             "out_gl", "t"}
     for metric, never, always in (("mse", -1.0, 1e9), ("vi", -1.0, 1e9), ("h_xy", -1.0, 1e9), ("h_yx", -1.0, 1e9),
-                                  ("nmi", 1e9, -1.0)):
+                                  ("nmi", 1e9, -1.0), ("ssim", 1e9, -2.0)):
         lo = br_evaluator(net, 4, C, loader, DEV, metric, never, ignore=(0,))
         hi = br_evaluator(net, 4, C, loader, DEV, metric, always, ignore=(0,))
         assert set(lo) == keys
@@ -99,7 +99,7 @@ def test_similarity_gated_evaluator_and_progressive_inference():
         # the first gated pair compares exits 0 and 1 and the image leaves AT exit 1: out_count[1] -> "b2_count"
         # (eval_br_sim.py:41-48,61-63); exit 0 can never be left at, it only provides the first map
         assert hi["b2_count"] == 4 and hi["b1_count"] == 0 and hi["count_out"] == 0
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):              # SSIM works on the label maps, not on the contingency table
         gate_function("ssim")
     # gate values vs the oracle on the materialised label maps
     X, _ = ds[1]
@@ -126,3 +126,7 @@ def test_similarity_gated_evaluator_and_progressive_inference():
                            "last_flops_2"}
     stop = eval_ee_deeplabv3(net, f_mse, 1e9, device=DEV, stop_at_exit=True)(X)
     assert "last" not in stop and torch.equal(stop["exit"], always["exit"])
+    from ee_semantic_segmentation_amd.sim_metrics import SSIM
+    s_never = eval_ee_deeplabv3(net, SSIM(C - 1), 2.0, less_than=False, device=DEV)(X)       # SSIM > 2 never holds
+    s_always = eval_ee_deeplabv3(net, SSIM(C - 1), -2.0, less_than=False, device=DEV)(X)
+    assert s_never["n"] == 4 and s_always["n"] == 2 and torch.equal(s_always["exit"], always["exit"])
