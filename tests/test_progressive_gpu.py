@@ -94,7 +94,9 @@ def test_conv_launches_skip_inactive_slots():
             out = torch.full_like(full, 7.0)
             with K.active_images(na):
                 K.conv_fwd(x, wf, s, p, d, relu=True, out=out)
-            if dtype == torch.float32 or live == 8:
+            if live == 0:
+                pass
+            elif dtype == torch.float32 or live == 8:
                 assert torch.equal(out[:live], full[:live]), (Cin, Cout, k, live)
             else:       # bf16: the same tiles, but tiles of the K-split tail may be whole tiles now (other rounding)
                 assert (out[:live].float() - full[:live].float()).abs().max().item() <= 8e-3 * full.float().abs().max().item()
