@@ -25,7 +25,8 @@ class ConvArgs(C.Structure):
                [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
                                        "smul", "off_h", "off_w", "tstep_h", "tstep_w", "sdiv",
                                        "ldy", "ldres", "relu", "dtype")] + \
-               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("n_active", C.c_void_p)]
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("n_active", C.c_void_p),
+                ("residual_mask", C.c_void_p), ("ld_residual_mask", C.c_int)]
 
 
 class WgradArgs(C.Structure):

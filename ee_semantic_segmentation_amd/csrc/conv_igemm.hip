@@ -36,7 +36,20 @@ struct ConvP {
     float* slabs;             // 256x256 kernel: fp32 partial tiles [tile][range][256*256]
     int pointwise;            // 256x256 kernel: 1x1, stride 1, no padding (source pixel = output pixel)
     const int* n_active;      // device count of the leading images that are computed at all (NULL = all)
+    const unsigned char* resmask;   // optional 1-bit mask of the residual (one byte per 16-byte chunk of a row, bn_apply_relu_mask)
+    int ldmask;                     // bytes per mask row
 };
+
+// residual chunk `q` (8 bf16) AND-ed with mask byte `mb`: element e survives iff bit e is set
+__device__ __forceinline__ i32x4 mask_chunk_bf16(i32x4 q, unsigned mb) {
+    i32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = (mb >> (2 * k)) & 1u, hi = (mb >> (2 * k + 1)) & 1u;
+        r[k] = (int)((unsigned)q[k] & ((lo ? 0x0000ffffu : 0u) | (hi ? 0xffff0000u : 0u)));
+    }
+    return r;
+}
 
 // progressive inference: a block whose first output pixel belongs to an image >= *n_active has nothing to do
 #define EESEG_ACTIVE_EXIT(first_px) \
@@ -849,6 +862,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                 if (res != nullptr) {
                     union { i32x4 q; T e[8]; } ur;
                     ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+                    if (p.resmask) ur.q = mask_chunk_bf16(ur.q, p.resmask[(size_t)m * p.ldmask + (cg >> 3)]);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(ur.e[e])));
                 }
@@ -1003,6 +1017,7 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
             if (full) {
                 union { i32x4 q; T e[8]; } ur;
                 ur.q = *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg);
+                if (p.resmask) ur.q = mask_chunk_bf16(ur.q, p.resmask[(size_t)m * p.ldmask + (cg >> 3)]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(to_f32(v[e]) + to_f32(ur.e[e]));
             } else {
@@ -1228,6 +1243,16 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
             for (int it = 0; it < 16; ++it) {
                 const int m = m0 + r0 + 8 * it;
                 rr[it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
+            }
+            if (p.resmask) {
+                unsigned mb[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int m = m0 + r0 + 8 * it;
+                    mb[it] = m < p.M ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0u;
+                }
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rr[it] = mask_chunk_bf16(rr[it], mb[it]);
             }
         }
 #pragma unroll
@@ -1505,6 +1530,10 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.tap_inner = g_conv_linear;
     p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.pointwise = 0;
     p.n_active = a->n_active;
+    p.resmask = a->residual_mask; p.ldmask = a->ld_residual_mask;
+    EESEG_CHECK(!a->residual_mask || (a->residual && a->dtype == EESEG_BF16 && a->ld_residual_mask >= a->Cout / 8 &&
+                                      a->Cout % 256 == 0 && a->sdiv == 1 && g_conv_pipe == 3),
+                EESEG_ERR_ARG, "conv_igemm: a residual mask needs a bf16 residual on the 256-tile / pointwise kernels (Cout %% 256 == 0)");
     EESEG_CHECK(!a->n_active || !a->stats, EESEG_ERR_ARG, "conv_igemm: n_active is an inference feature (no BN statistics)");
     p.vec_ok = (((uintptr_t)a->y & 15) == 0) && (a->ldy % epc == 0) &&
                (!a->residual || ((((uintptr_t)a->residual & 15) == 0) && (a->ldres % epc == 0)));

@@ -39,6 +39,7 @@ class Config:
         self.accumulate = False              # arena mode: add to the stored gradients instead of overwriting
         self.step_counter = None             # device int64[1]; lets a captured graph draw fresh dropout masks
         self.on_unit_done = None             # callable(unit_id): gradient bucket scheduling (GradReducer)
+        self.fuse_block_residual = __import__("os").environ.get("EESEG_FUSE_BLOCK_RESIDUAL", "1") != "0"   # identity blocks: dout * mask is added by conv1's data-gradient, not written by BN backward
         self.overlap_wgrad = False           # opt-in (measured +-0 with the 256-tile kernels): weight-gradient on a side stream, concurrent with the data-gradient:
         self._side = None                    # the two kernels fill each other's partially filled last block round
         self._side_busy = False
@@ -363,9 +364,10 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
     return y, (x, c, None, mi, count, relu, ss)
 
 
-def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False):
+def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False, dx_add=None):
     """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
-    parameter gradients are None in arena mode (written in place)."""
+    parameter gradients are None in arena mode (written in place).  dx_add=(t, mask): the data-gradient adds
+    t * mask (bit mask) in its epilogue - the masked block gradient of a bottleneck, never materialised."""
     x, c, y, mi, count, relu, ss = st[:7]
     frozen = len(st) > 7 and st[7]
     pair = cfg.gview(bn)
@@ -413,7 +415,7 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         # BatchNorm-backward passes of the layer below (HBM-bound, few registers, small LDS: their blocks fit on a CU next
         # to a one-block-per-CU MFMA kernel) instead of competing with the data-gradient for the CUs
         _, wb = packed(conv, dc.dtype)
-        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)
         cur = torch.cuda.current_stream(dc.device)
         side = cfg.side_stream(dc.device)
         side.wait_stream(cur)
@@ -433,12 +435,12 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         cfg._side_busy = True
         cfg._side_keep.append((x, dc, dwp))
         _, wb = packed(conv, dc.dtype)
-        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+        dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)
     else:
         dwp = wgrad()
         if need_dx:
             _, wb = packed(conv, dc.dtype)
-            dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum)
+            dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)
     return dx, dres, dwp, dgamma, dbeta
 
 
@@ -519,7 +521,13 @@ def bottleneck_fwd(cfg, x, blk, train, frozen=False):
 def bottleneck_bwd(cfg, state, dout, blk):
     """Returns (dx, [grads in blk.param_list() order])."""
     s1, s2, s3, sd = state
-    dy2, dres, dw3, dg3, db3 = conv_bn_bwd(cfg, s3, dout, blk.conv3, blk.bn3, want_dres=True)
+    # identity blocks: the block gradient that flows past the three convs is dout * (ReLU mask of the block output).
+    # The data-gradient of conv1 adds it in its epilogue from dout and the 1-bit mask bn_apply left, so BatchNorm
+    # backward writes one tensor less (bf16 layers on the 256-tile / pointwise kernels; cfg.fuse_block_residual)
+    mask3 = s3[2]
+    fuse = (sd is None and cfg.fuse_block_residual and mask3 is not None and mask3.dtype == torch.uint8 and
+            dout.is_cuda and K.masked_residual_ok(dout.dtype, dout.shape[-1]) and blk.conv1.stride[0] == 1)
+    dy2, dres, dw3, dg3, db3 = conv_bn_bwd(cfg, s3, dout, blk.conv3, blk.bn3, want_dres=not fuse)
     dy1, _, dw2, dg2, db2 = conv_bn_bwd(cfg, s2, dy2, blk.conv2, blk.bn2)
     grads = [None] * 9
     if sd is not None:
@@ -527,6 +535,9 @@ def bottleneck_bwd(cfg, state, dout, blk):
         dxd, _, dwd, dgd, dbd = conv_bn_bwd(cfg, sd, dres, ds[0], ds[1])
         dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_accum=dxd)
         extra = [dwd, dgd, dbd]
+    elif fuse:
+        dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_add=(dout, mask3))
+        extra = []
     else:
         dx, _, dw1, dg1, db1 = conv_bn_bwd(cfg, s1, dy1, blk.conv1, blk.bn1, dx_accum=dres)
         extra = []

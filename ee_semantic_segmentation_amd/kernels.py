@@ -158,7 +158,7 @@ def conv_out_size(h, k, stride, pad, dil):
 
 # ------------------------------------------------------------------ conv ----
 def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tstep, sdiv, ldy,
-               scale=None, shift=None, residual=None, ldres=0, stats=None, relu=False):
+               scale=None, shift=None, residual=None, ldres=0, stats=None, relu=False, resmask=None):
     a = ConvArgs()
     a.x, a.w, a.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
     a.scale = 0 if scale is None else scale.data_ptr()
@@ -171,6 +171,8 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     ws = _conv_ws(x.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     a.n_active = 0 if (ACTIVE is None or stats is not None) else ACTIVE.data_ptr()
+    a.residual_mask = 0 if resmask is None else resmask.data_ptr()
+    a.ld_residual_mask = 0 if resmask is None else resmask.shape[-1]
     ev = _prof_begin()
     check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
     if ev is not None:
@@ -210,14 +212,29 @@ def conv_fwd(x, w, stride=1, pad=0, dil=1, *, want_stats=False, scale=None, shif
     return out, partials
 
 
-def conv_dgrad(dy, w_bwd, in_hw, stride=1, pad=0, dil=1, *, accumulate_into=None):
+def masked_residual_ok(dtype, cin):
+    """Can conv_dgrad(..., add=(t, mask)) run for a data-gradient with `cin` output channels?"""
+    return dtype == torch.bfloat16 and cin % 256 == 0 and lib().eeseg_get_option(1) == 3
+
+
+def conv_dgrad(dy, w_bwd, in_hw, stride=1, pad=0, dil=1, *, accumulate_into=None, add=None):
     """dy [N,Ho,Wo,Cout]; w_bwd packed CRSK [Cin,R,S,Cout].  Returns dx [N,H,W,Cin]
-    (added into `accumulate_into` in place when given)."""
+    (added into `accumulate_into` in place when given).  add=(t, mask): dx = dgrad + t * mask with `mask` the 1-bit
+    ReLU mask of bn_apply (one byte per 16-byte chunk) - nothing is modified in place."""
     _need_cuda(dy, w_bwd)
     N, Ho, Wo, Cout = dy.shape
     Cin, R, S, Cout2 = w_bwd.shape
     assert Cout2 == Cout and dy.is_contiguous() and w_bwd.is_contiguous() and w_bwd.dtype == dy.dtype
     H, W = in_hw
+    if add is not None:
+        assert accumulate_into is None and stride == 1
+        t, mask = add
+        assert t.shape == (N, H, W, Cin) and t.dtype == dy.dtype and mask.dtype == torch.uint8 and mask.is_contiguous()
+        assert mask.shape[-1] * 8 == Cin and mask.numel() == N * H * W * (Cin // 8)
+        dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
+        _conv_call(dy, w_bwd, dx, N, Ho, Wo, Cout, H, W, Cin, R, S, 1, pad, -dil, stride, Cin, residual=t,
+                   ldres=rows_ld(t)[2], resmask=mask)
+        return dx
     if accumulate_into is not None:
         dx = accumulate_into
         assert dx.shape == (N, H, W, Cin) and dx.dtype == dy.dtype

@@ -98,6 +98,10 @@ typedef struct {
                                      blocks whose pixels all belong to later images return at once.  Batched progressive
                                      early-exit inference keeps the images still in flight in the leading slots and
                                      their count on the device, so no exit decision is ever read back by the host. */
+    const uint8_t* residual_mask; /* optional (NULL = none): the residual is multiplied by a 1-bit mask before it is added - one byte */
+    int ld_residual_mask;         /* per 16-byte chunk of a residual row, bit e = element e (the ReLU mask eeseg_bn_apply_relu_mask
+                                     writes), ld = bytes per mask row.  Lets the data-gradient of a bottleneck's first conv add the
+                                     masked block gradient itself, so BatchNorm backward need not write it (bf16, Cout % 256 == 0). */
 } eeseg_conv_args;
 int64_t eeseg_conv_workspace(void);
 int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */

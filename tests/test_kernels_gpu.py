@@ -901,3 +901,46 @@ def test_ce_thread_per_span_kernels_match_half_wave_kernels(hw, HW, Cc):
     assert abs(out[0][0][0] - out[1][0][0]) <= 2e-6 * abs(out[0][0][0])
     close(out[1][1], out[0][1], 2e-5, "ce bwd span vs half-wave")
     assert out[1][1][..., Cc:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 31, 256, 1024), (2, 33, 31, 1024, 256), (1, 40, 52, 512, 2048)],
+                         ids=["pw-256-1024", "big-1024-256", "pw-512-2048"])
+def test_dgrad_adds_masked_residual(shape):
+    """conv_dgrad(add=(t, mask)): dx = dgrad(dy) + t * mask with the 1-bit ReLU mask of bn_apply (eeseg_conv_args.
+    residual_mask), on the pointwise and the 256-tile kernel (incl. its K-split tail), against the two-step form."""
+    N, H, W, Cdy, Cdx = shape
+    g = torch.Generator().manual_seed(4)
+    dy = torch.randn(N, H, W, Cdy, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(Cdy, Cdx, 1, 1, generator=g) * 0.05).to(DEV)          # forward conv Cdx -> Cdy
+    _, wb = K.pack_weight(wt, torch.bfloat16)
+    c = torch.randn(N, H, W, Cdx, generator=g).to(DEV).bfloat16()
+    res = torch.randn(N, H, W, Cdx, generator=g).to(DEV).bfloat16()
+    ss = torch.stack([torch.rand(Cdx, generator=g) + 0.5, torch.randn(Cdx, generator=g) * 0.1]).to(DEV)
+    y, mask = K.bn_apply(c, ss, residual=res, relu=True, want_mask=True)
+    t = torch.randn(N, H, W, Cdx, generator=g).to(DEV).bfloat16()
+    want = K.conv_dgrad(dy, wb, (H, W), accumulate_into=(t * (y > 0)).contiguous())
+    got = K.conv_dgrad(dy, wb, (H, W), add=(t, mask))
+    assert torch.equal(got, want)
+    assert float((y > 0).float().mean()) > 0.2 and float((y > 0).float().mean()) < 0.8
+
+
+def test_identity_block_backward_with_fused_residual_is_bit_identical():
+    """engine.Config.fuse_block_residual: the block gradient dout * mask is added by conv1's data-gradient epilogue
+    instead of being written by BatchNorm backward and read back - same arithmetic, one tensor pass less."""
+    from ee_semantic_segmentation_amd import engine as E
+    from ee_semantic_segmentation_amd.nn_modules import Bottleneck
+    outs = []
+    for fuse in (False, True):
+        cfg = E.Config()
+        cfg.compute_dtype = torch.bfloat16
+        cfg.fuse_block_residual = fuse
+        torch.manual_seed(3)
+        blk = Bottleneck(1024, 256, 1, None, 2, cfg=cfg).to(DEV).train()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16().requires_grad_(True)
+        gy = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16()
+        blk(x).backward(gy)
+        outs.append([x.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    assert torch.equal(outs[0][0], outs[1][0])            # the input gradient: same kernels, same arithmetic
+    for a, b in zip(outs[0][1:], outs[1][1:]):            # weight gradients are summed with fp32 atomics: last-bit noise
+        close(a, b, 1e-3, "parameter gradient")
