@@ -14,6 +14,9 @@ from . import kernels as K
 from .from_deepv3_new import ExitLogits
 
 
+CHECK_LABELS = __import__("os").environ.get("EESEG_CHECK_LABELS") == "1"
+
+
 def _as_lowres(y, C):
     """[B,C,H,W] full-resolution logits -> NHWC [B,H,W,32] fp32 (identity upsample)."""
     B, Cc, H, W = y.shape
@@ -74,6 +77,14 @@ def fused_cross_entropy(lowres, target, num_classes, size, ignore_index=-100, re
     target = target.contiguous()
     if target.dtype != torch.int64:
         target = target.long()
+    if CHECK_LABELS:
+        # torch's CrossEntropyLoss asserts on a label outside [0, C) that is not ignore_index; the fused kernel skips
+        # such pixels.  The check costs a device->host sync, so it is a debugging switch (EESEG_CHECK_LABELS=1): it
+        # catches e.g. VOC's 255 border label meeting the default ignore_index = -100.
+        bad = ((target < 0) | (target >= num_classes)) & (target != ignore_index)
+        if bool(bad.any()):
+            raise ValueError(f"{int(bad.sum())} target values outside [0, {num_classes}) that are not ignore_index="
+                             f"{ignore_index} (first: {int(target[bad][0])})")
     H, W = size
     return _FusedCE.apply(target, num_classes, H, W, int(ignore_index), reduction == "mean", comm, *lowres)
 
