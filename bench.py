@@ -98,7 +98,9 @@ class Run:
         net = branchyDeepv3(None, f"deeplabv3_{arch}", branches, img, count_branches=False, num_classes=classes,
                             compute_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32,
                             fused_outputs=True).to(dev)
-        net.cfg.sync_bn = bool(sync_bn and world > 1)
+        # EESEG_FORCE_ALLREDUCE=1 (with RANK/WORLD_SIZE=1 set): a 1-rank RCCL group still issues every collective -
+        # rehearses the N > 1 graph (SyncBN all-reduces, CE count, arena buckets) on one GPU
+        net.cfg.sync_bn = bool(sync_bn and (world > 1 or os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"))
         net.cfg.overlap_wgrad = args.overlap_wgrad
         broadcast_parameters(net)
         self.E = net.n_branches + 1

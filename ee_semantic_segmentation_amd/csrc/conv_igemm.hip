@@ -1332,6 +1332,260 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
     PW_STAMP(6);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary pointwise kernel for Cin = 256 (the layer-3 bottleneck convs that EXPAND: conv3 forward and the
+// data-gradient of conv1, 47 calls of a ResNet-101 step).  conv_pw_kernel's K loop is bound by bytes in flight: a block
+// holds two K tiles (48 KiB) of LDS-DMA in the air and must re-fetch its 128-KiB weight tile from L2 for every pixel tile
+// (192 KiB of DMA per 64 KiB of output).  Here a block is PERSISTENT over the pixel tiles of one cout tile and keeps
+// its weights where nothing else competes for space: in REGISTERS, as MFMA A fragments (64 couts x 256 channels per
+// wave = 128 VGPRs).  Only the activations stream: 64 pixels x 256 channels = one 32-KiB LDS slot per half tile, two
+// slots, so the next half tile's loads are in flight during the whole MFMA + epilogue of the current one, and the
+// epilogue stages its 64 x 256 output through the slot it has just consumed (no staging area of its own): 72 KiB of
+// LDS, two blocks per CU.  Per half tile: 64 MFMAs per wave (1.1 us), epilogue beside the other block's MFMAs.
+constexpr int WS_K = 256;
+constexpr int WS_HALF = 64;                        // pixels per half tile
+constexpr int WS_ROWB = WS_K * 2;                  // 512-byte LDS rows: X [px][256 ch] and the staged output [px][256 cout]
+constexpr int WS_SLOT = WS_HALF * WS_ROWB;         // 32 KiB
+constexpr int WS_LDS = 2 * WS_SLOT + 4 * 2 * 256 * 4 + 16;
+
+__global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
+    typedef bf16_t T;
+    typedef Mma<T>::Frag Frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __shared__ __attribute__((aligned(16))) char smem[WS_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr_ = lane & 31, fh_ = lane >> 5, fx_ = fr_ & 15;
+#ifdef EESEG_PW_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) of the block's second tile into the conv workspace
+    int stamp_tile = 0;
+#define WS_STAMP(i) if (tid == 0 && p.slabs && (stamp_tile == 1 || (i) == 0 || (i) == 1 || (i) == 15)) \
+        reinterpret_cast<unsigned long long*>(p.slabs)[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define WS_STAMP(i)
+#endif
+    WS_STAMP(0);
+    // block -> (cout tile, tile sequence): the n_tiles blocks that walk the same pixel tiles at the same time have equal
+    // blockIdx % 8, i.e. share an XCD and its L2 under round-robin placement (speed only): X comes from HBM once
+    const int per = 8 * p.n_tiles;
+    const int grp = blockIdx.x / per, g = blockIdx.x % per;
+    const int nt = g >> 3, seq = grp * 8 + (g & 7), nseq = (gridDim.x / per) * 8;
+    const int n0 = nt * 256;
+    const int n_m = p.m_tiles;                                   // 128-pixel tiles (= BN statistic rows)
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+    // DMA role: one wave instruction = 2 rows x 512 B; instr q of wave w covers rows (w*8+q)*2 + (lane>>5)
+    const int drow = lane >> 5, dslot = lane & 31;
+    auto issue = [&](int mt, int half, bool live) {
+        char* sx = smem + half * WS_SLOT;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = (wave * 8 + q) * 2 + drow;
+            const int m = mt * 128 + half * WS_HALF + r;
+            const uint32_t voff = (live && m < p.M) ? (uint32_t)(m * WS_ROWB + ((dslot ^ (r & 15)) << 4)) : EESEG_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 8 + q) * 1024), 16, (int)voff, 0, 0, 0);
+        }
+    };
+    int mt = seq;
+    issue(mt, 0, mt < n_m);
+    issue(mt, 1, mt < n_m);
+
+    // the weights of this wave's 64 couts, all of K, as A fragments (read once per block)
+    Frag a[2][16];
+    {
+        const T* w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* wr = w + (size_t)(n0 + wave * 64 + i * 32 + fr_) * WS_K + fh_ * 8;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(wr + ks * 16);
+        }
+    }
+    WS_STAMP(1);
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    T* yout = reinterpret_cast<T*>(p.y);
+    float* sRed = reinterpret_cast<float*>(smem + 2 * WS_SLOT);   // [4 waves][2][256]
+    const int c_ = tid & 31, r0_ = tid >> 5;                      // epilogue role: 16-byte chunk c of rows r0 + 8*it
+
+    for (; mt < n_m; mt += nseq) {
+        const int nxt = mt + nseq;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            char* slot = smem + half * WS_SLOT;
+            // lane coordinates made opaque per half tile: every LDS / global address below is then recomputed here instead
+            // of being hoisted out of the tile loop, where ~60 loop-invariant addresses would push the weights out of registers
+            int fr = fr_, fh = fh_, fx = fx_, c = c_, r0 = r0_;
+            asm volatile("" : "+v"(fr), "+v"(fh), "+v"(fx), "+v"(c), "+v"(r0));
+            const int cg = n0 + c * 8;
+            WS_STAMP(2 + half * 6);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // this half's X landed (the 16 youngest: the other half's loads + stores)
+            BIG_BARRIER();
+            WS_STAMP(3 + half * 6);
+            // two passes of 32 pixels (32 MFMAs each): the accumulators of a pass are rounded to bf16 at once, so 16
+            // registers instead of 32 wait for the staging while the weights hold 128 (no scale / shift here: the training
+            // forward and the data-gradient have none, and loading 64 per-lane coefficients made the allocator spill the weights)
+            bf16x4 packed[2][2][4];                               // [pixel tile j][cout tile i][register group]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 acc[2];
+                const char* r = slot + (j * 32 + fr) * WS_ROWB;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {                  // 2 k-steps at a time: 2 B fragments live
+                    Frag b[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const Frag*>(r + ((((kk * 2 + u) * 2 + fh) ^ fx) << 4));
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (kk == 0 && u == 0) {
+                                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], z, 0, 0, 0);
+                            } else {
+                                Mma<T>::run(a[i][kk * 2 + u], b[u], acc[i]);
+                            }
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        T v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][4 * gq + e]);
+                        packed[j][i][gq] = bf16x4{v[0], v[1], v[2], v[3]};
+                    }
+            }
+            WS_STAMP(4 + half * 6);
+            __syncthreads();                                      // every wave has read its fragments: the slot becomes the staging area
+            // ---- stage [px][cout] (16-byte chunks XOR-ed with px & 15: the 512-byte pitch maps every row to the same banks) ----
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int cl = wave * 64 + i * 32 + 8 * gq + 4 * fh;
+                    char* d = slot + fr * WS_ROWB + ((((cl >> 3) ^ fx) << 4) | ((cl & 4) << 1));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x4*>(d + j * 32 * WS_ROWB) = packed[j][i][gq];
+                }
+            __syncthreads();
+            WS_STAMP(5 + half * 6);
+            // ---- two passes of 4 rows x 16 B per thread: read back, residual (+ mask), ReLU, store, BN partial sums.  The next
+            //      half tile's DMA is issued after the second read-back (the slot is free then) and after the residual loads
+            //      (vmcnt retires in order: a wait for a load issued behind the DMA would wait for the DMA) ----
+            const int mh = mt * 128 + half * WS_HALF;
+            f32x2 a1[4], a2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                i32x4 rq[4], rr[4];
+                unsigned mb[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = r0 + 8 * (ps * 4 + it);
+                    rq[it] = *reinterpret_cast<const i32x4*>(slot + row * WS_ROWB + ((c ^ (row & 15)) << 4));
+                }
+                if (res != nullptr) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int m = mh + r0 + 8 * (ps * 4 + it);
+                        rr[it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
+                        mb[it] = (p.resmask && m < p.M) ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0xffu;
+                    }
+                }
+                if (ps == 1) {
+                    __syncthreads();                              // staging consumed by every thread: the slot is free
+                    issue(nxt, half, nxt < n_m);                  // next tile's half into it (out-of-range loads past the end)
+                }
+                if (res != nullptr || p.relu) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        union { i32x4 q; T e[8]; } u, ur;
+                        u.q = rq[it];
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = to_f32(u.e[e]);
+                        if (res != nullptr) {
+                            ur.q = p.resmask ? mask_chunk_bf16(rr[it], mb[it]) : rr[it];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(ur.e[e])));
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) u.e[e] = from_f32<T>(f[e]);
+                        rq[it] = u.q;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = mh + r0 + 8 * (ps * 4 + it);
+                    if (m < p.M) *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = rq[it];
+                }
+                if (p.stats) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        if (mh + r0 + 8 * (ps * 4 + it) < p.M) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned w = (unsigned)rq[it][k];
+                                const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                                a1[k] += f;
+                                a2[k] += f * f;
+                            }
+                        }
+                    }
+                }
+            }
+            WS_STAMP(6 + half * 6);
+            if (p.stats) {                                        // one stat row per 128-pixel tile: the first half writes it,
+                                                                  // the second adds (same thread, in program order)
+                float s1[8], s2[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[2 * k] = a1[k][0]; s1[2 * k + 1] = a1[k][1];
+                    s2[2 * k] = a2[k][0]; s2[2 * k + 1] = a2[k][1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += __shfl_xor(s1[e], 32);
+                    s2[e] += __shfl_xor(s2[e], 32);
+                }
+                if (lane < 32) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        sRed[(wave * 2 + 0) * 256 + lane * 8 + e] = s1[e];
+                        sRed[(wave * 2 + 1) * 256 + lane * 8 + e] = s2[e];
+                    }
+                }
+                __syncthreads();
+                const int col = tid;
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    const float t = sRed[(0 * 2 + which) * 256 + col] + sRed[(1 * 2 + which) * 256 + col] +
+                                    sRed[(2 * 2 + which) * 256 + col] + sRed[(3 * 2 + which) * 256 + col];
+                    float* dst = p.stats + ((size_t)mt * 2 + which) * p.Cout + n0 + col;
+                    *dst = half == 0 ? t : *dst + t;
+                }
+                __syncthreads();                                  // sRed is rewritten by the next half
+            }
+            WS_STAMP(7 + half * 6);
+        }
+#ifdef EESEG_PW_STAMPS
+        ++stamp_tile;
+#endif
+    }
+    WS_STAMP(15);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing out-of-range DMAs still write into LDS
+}
+
+int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwise layers on the weight-stationary kernel
+
 int g_conv_pw_max_k = 1280;   // EESEG_OPT_CONV_PW_MAX_K: pointwise bf16 layers with Cin <= this use conv_pw_kernel (0 = never)
 
 int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K range of a split tail tile holds at least
@@ -1460,6 +1714,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_pw_max_k = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_PWS && (value == 0 || value == 1)) {
+        g_conv_pws = value;
+        return EESEG_OK;
+    }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);
     return EESEG_ERR_ARG;
 }
@@ -1479,6 +1737,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_COLREDUCE_BLOCKS: return g_colreduce_blocks;
         case EESEG_OPT_CONV_SPLIT_MIN_K: return g_conv_big_split_min_k;
         case EESEG_OPT_CONV_PW_MAX_K: return g_conv_pw_max_k;
+        case EESEG_OPT_CONV_PWS: return g_conv_pws;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1546,6 +1805,21 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
         // two 128x256 blocks per CU, so one block's epilogue runs beside the other's K loop (measured at 32 x 65 x 65:
         // 256->1024 150 -> 133 us, with a residual 230 -> 145 us, 512->2048 410 -> 370 us; contracting layers such as
         // 1024->256 stay on the 256-tile kernel: 101 vs 106 us, their K loop dominates and the bigger tile re-reads W less)
+        if (p.pointwise && g_conv_pws && a->Cin == WS_K && !a->n_active && !a->scale && !a->shift && a->ldy % 8 == 0 &&
+            (a->Cout >= 2 * a->Cin || a->residual) && M >= 128 * 128) {
+            // weight-stationary persistent form: grid = whole groups of 8 blocks per cout tile, two blocks per CU
+            p.n_tiles = a->Cout / 256;
+            const int per = 8 * p.n_tiles;
+            int groups = 512 / per;
+            if (groups < 1) groups = 1;
+            while (groups > 1 && (groups - 1) * 8 >= p.m_tiles) --groups;     // no more sequences than tiles
+#ifdef EESEG_PW_STAMPS
+            p.slabs = reinterpret_cast<float*>(a->workspace);
+#endif
+            hipLaunchKernelGGL(conv_pws_kernel, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
+            EESEG_LAUNCH_CHECK();
+            return EESEG_OK;
+        }
         if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 && (a->Cout >= 2 * a->Cin || a->residual)) {
             p.n_tiles = a->Cout / PW_BN;
 #ifdef EESEG_PW_STAMPS

@@ -590,6 +590,7 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
 PW_CASES = [
     # N, H, W, Cin, Cout - pointwise layers of the two-blocks-per-CU 128x256 kernel (conv_pw_kernel: Cin <= 1280)
     (2, 65, 65, 256, 1024),       # bottleneck conv3: 67 pixel tiles (ragged last one) x 4 cout tiles
+    (5, 65, 65, 256, 1024),       # the same on the weight-stationary persistent kernel (Cin = 256, >= 128 tiles): 166 tiles, ragged
     (3, 33, 31, 1024, 256),       # bottleneck conv1: 32 K tiles (contracting: only its residual forms go to the kernel)
     (1, 9, 11, 64, 256),          # fewer pixels than one tile, two K tiles (the pipeline prologue covers the whole K loop)
     (2, 40, 52, 1280, 256),       # ASPP projection: 40 K tiles
@@ -618,8 +619,10 @@ def test_conv_pointwise_kernel_vs_torch(case):
     res = rnd(dtype, *y.shape, seed=4)
     want2 = torch.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
     outs = {}
-    for name, maxk in (("pw", 1280), ("big", 0)):
+    variants = [("pw", 1280, 1), ("big", 0, 0)] + ([("pw128", 1280, 0)] if Cin == 256 and N * H * W >= 128 * 128 else [])
+    for name, maxk, ws in variants:
         lib().eeseg_set_option(13, maxk)
+        lib().eeseg_set_option(14, ws)
         try:
             assert lib().eeseg_get_option(13) == maxk
             yd, part = K.conv_fwd(xd, wf, want_stats=True)
@@ -629,6 +632,10 @@ def test_conv_pointwise_kernel_vs_torch(case):
             outs[name] = (yd, K.reduce_partials(part), wide, y2)
         finally:
             lib().eeseg_set_option(13, 1280)
+            lib().eeseg_set_option(14, 1)
+    if "pw128" in outs:                 # weight-stationary vs 128x256 kernel: same MFMAs in the same K order
+        assert torch.equal(outs["pw"][0], outs["pw128"][0])
+        close(outs["pw"][1], outs["pw128"][1], 1e-5, "BN partial sums")
     for name, (yd, sums, wide, y2) in outs.items():
         close(nchw(yd), y, tol(dtype), f"{name} fwd")
         ys = yd.float().reshape(-1, Cout)
@@ -903,8 +910,9 @@ def test_ce_thread_per_span_kernels_match_half_wave_kernels(hw, HW, Cc):
     assert out[1][1][..., Cc:].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("shape", [(2, 33, 31, 256, 1024), (2, 33, 31, 1024, 256), (1, 40, 52, 512, 2048)],
-                         ids=["pw-256-1024", "big-1024-256", "pw-512-2048"])
+@pytest.mark.parametrize("shape", [(2, 33, 31, 256, 1024), (2, 33, 31, 1024, 256), (1, 40, 52, 512, 2048),
+                                   (5, 65, 65, 256, 1024)],
+                         ids=["pw-256-1024", "big-1024-256", "pw-512-2048", "ws-256-1024"])
 def test_dgrad_adds_masked_residual(shape):
     """conv_dgrad(add=(t, mask)): dx = dgrad(dy) + t * mask with the 1-bit ReLU mask of bn_apply (eeseg_conv_args.
     residual_mask), on the pointwise and the 256-tile kernel (incl. its K-split tail), against the two-step form."""
@@ -926,21 +934,24 @@ def test_dgrad_adds_masked_residual(shape):
 
 def test_identity_block_backward_with_fused_residual_is_bit_identical():
     """engine.Config.fuse_block_residual: the block gradient dout * mask is added by conv1's data-gradient epilogue
-    instead of being written by BatchNorm backward and read back - same arithmetic, one tensor pass less."""
+    instead of being written by BatchNorm backward and read back - same arithmetic, one tensor pass less.  Both forms
+    run on the SAME forward state (two forwards of a small block differ in the last bit of the BatchNorm statistics -
+    the K-split tail sums its partial statistics with fp32 atomics - and a ReLU mask then flips here and there)."""
     from ee_semantic_segmentation_amd import engine as E
     from ee_semantic_segmentation_amd.nn_modules import Bottleneck
+    cfg = E.Config()
+    cfg.compute_dtype = torch.bfloat16
+    torch.manual_seed(3)
+    blk = Bottleneck(1024, 256, 1, None, 2, cfg=cfg).to(DEV).train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16()
+    gy = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16()
+    _, st = E.bottleneck_fwd(cfg, x, blk, True)
     outs = []
     for fuse in (False, True):
-        cfg = E.Config()
-        cfg.compute_dtype = torch.bfloat16
         cfg.fuse_block_residual = fuse
-        torch.manual_seed(3)
-        blk = Bottleneck(1024, 256, 1, None, 2, cfg=cfg).to(DEV).train()
-        g = torch.Generator().manual_seed(6)
-        x = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16().requires_grad_(True)
-        gy = torch.randn(2, 33, 29, 1024, generator=g).to(DEV).bfloat16()
-        blk(x).backward(gy)
-        outs.append([x.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+        dx, grads = E.bottleneck_bwd(cfg, st, gy.clone(), blk)
+        outs.append([dx.clone()] + [t.clone() for t in grads])
     assert torch.equal(outs[0][0], outs[1][0])            # the input gradient: same kernels, same arithmetic
     for a, b in zip(outs[0][1:], outs[1][1:]):            # weight gradients are summed with fp32 atomics: last-bit noise
         close(a, b, 1e-3, "parameter gradient")
