@@ -1081,7 +1081,10 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
 // Here a tile is 128 pixels x 256 couts on 4 waves (64 couts x 128 pixels per wave: the same per-wave
 // shape, so the same 24 B/clk of LDS fragment reads per MFMA-bound wave) and a block needs 74 KiB of
 // LDS and <= 256 VGPRs -> TWO blocks per CU: while one streams its output, the other owns the MFMA pipes
-// and keeps loads in flight.  K tile = 32 channels (64-byte LDS rows), three stages of LDS-DMA
+// and keeps loads in flight.  (Tried and dropped: separate rings for activations (6 deep, issued by waves 0-1) and weights
+// (2 deep, waves 2-3) so that HBM-latency and L2-latency loads do not share one in-order vmcnt: 256->1024 133 -> 140 us,
+// 1024->256 127 us vs 103 on the 256-tile kernel - the weight tile's round trip is then exposed on every K tile.)
+// K tile = 32 channels (64-byte LDS rows), three stages of LDS-DMA
 // (buffer_load ... lds) in flight across one raw barrier per K tile; XOR swizzle on the SOURCE chunk
 // (chunk ^ ((row >> 2) & 3): conflict-free ds_read_b128 for a 64-byte row pitch, MI355X_MICROARCH.md LDS).
 constexpr int PW_BM = 128, PW_BN = 256;
@@ -1584,6 +1587,7 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing out-of-range DMAs still write into LDS
 }
 
+int g_conv_pw_all = 0;        // EESEG_OPT_CONV_PW_ALL: 1 = every eligible pointwise layer on conv_pw_kernel, not only the output-heavy ones
 int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwise layers on the weight-stationary kernel
 
 int g_conv_pw_max_k = 1280;   // EESEG_OPT_CONV_PW_MAX_K: pointwise bf16 layers with Cin <= this use conv_pw_kernel (0 = never)
@@ -1714,6 +1718,10 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_pw_max_k = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_PW_ALL && (value == 0 || value == 1)) {
+        g_conv_pw_all = value;
+        return EESEG_OK;
+    }
     if (key == EESEG_OPT_CONV_PWS && (value == 0 || value == 1)) {
         g_conv_pws = value;
         return EESEG_OK;
@@ -1738,6 +1746,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_SPLIT_MIN_K: return g_conv_big_split_min_k;
         case EESEG_OPT_CONV_PW_MAX_K: return g_conv_pw_max_k;
         case EESEG_OPT_CONV_PWS: return g_conv_pws;
+        case EESEG_OPT_CONV_PW_ALL: return g_conv_pw_all;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
@@ -1806,8 +1815,9 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
         // 256->1024 150 -> 133 us, with a residual 230 -> 145 us, 512->2048 410 -> 370 us; contracting layers such as
         // 1024->256 stay on the 256-tile kernel: 101 vs 106 us, their K loop dominates and the bigger tile re-reads W less)
         if (p.pointwise && g_conv_pws && a->Cin == WS_K && !a->n_active && !a->scale && !a->shift && a->ldy % 8 == 0 &&
-            (a->Cout >= 2 * a->Cin || a->residual) && M >= 128 * 128) {
-            // weight-stationary persistent form: grid = whole groups of 8 blocks per cout tile, two blocks per CU
+            (a->Cout >= 2 * a->Cin || a->residual) && M >= 512 * 128) {
+            // weight-stationary persistent form (only where a block walks >= 4 pixel tiles: loading its 128 KiB of weights into
+            // registers costs 6.6 us): grid = whole groups of 8 blocks per cout tile, two blocks per CU
             p.n_tiles = a->Cout / 256;
             const int per = 8 * p.n_tiles;
             int groups = 512 / per;
@@ -1820,7 +1830,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }
-        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 && (a->Cout >= 2 * a->Cin || a->residual)) {
+        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 && (g_conv_pw_all || a->Cout >= 2 * a->Cin || a->residual)) {
             p.n_tiles = a->Cout / PW_BN;
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);

@@ -590,7 +590,7 @@ def test_conv_256_tile_kernel_matches_the_128_tile_kernel(shape):
 PW_CASES = [
     # N, H, W, Cin, Cout - pointwise layers of the two-blocks-per-CU 128x256 kernel (conv_pw_kernel: Cin <= 1280)
     (2, 65, 65, 256, 1024),       # bottleneck conv3: 67 pixel tiles (ragged last one) x 4 cout tiles
-    (5, 65, 65, 256, 1024),       # the same on the weight-stationary persistent kernel (Cin = 256, >= 128 tiles): 166 tiles, ragged
+    (16, 65, 65, 256, 1024),      # the same on the weight-stationary persistent kernel (Cin = 256, >= 512 tiles): 529 tiles, ragged
     (3, 33, 31, 1024, 256),       # bottleneck conv1: 32 K tiles (contracting: only its residual forms go to the kernel)
     (1, 9, 11, 64, 256),          # fewer pixels than one tile, two K tiles (the pipeline prologue covers the whole K loop)
     (2, 40, 52, 1280, 256),       # ASPP projection: 40 K tiles
@@ -619,7 +619,7 @@ def test_conv_pointwise_kernel_vs_torch(case):
     res = rnd(dtype, *y.shape, seed=4)
     want2 = torch.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
     outs = {}
-    variants = [("pw", 1280, 1), ("big", 0, 0)] + ([("pw128", 1280, 0)] if Cin == 256 and N * H * W >= 128 * 128 else [])
+    variants = [("pw", 1280, 1), ("big", 0, 0)] + ([("pw128", 1280, 0)] if Cin == 256 and N * H * W >= 512 * 128 else [])
     for name, maxk, ws in variants:
         lib().eeseg_set_option(13, maxk)
         lib().eeseg_set_option(14, ws)
@@ -911,7 +911,7 @@ def test_ce_thread_per_span_kernels_match_half_wave_kernels(hw, HW, Cc):
 
 
 @pytest.mark.parametrize("shape", [(2, 33, 31, 256, 1024), (2, 33, 31, 1024, 256), (1, 40, 52, 512, 2048),
-                                   (5, 65, 65, 256, 1024)],
+                                   (16, 65, 65, 256, 1024)],
                          ids=["pw-256-1024", "big-1024-256", "pw-512-2048", "ws-256-1024"])
 def test_dgrad_adds_masked_residual(shape):
     """conv_dgrad(add=(t, mask)): dx = dgrad(dy) + t * mask with the 1-bit ReLU mask of bn_apply (eeseg_conv_args.
