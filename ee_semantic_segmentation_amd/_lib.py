@@ -26,7 +26,8 @@ class ConvArgs(C.Structure):
                                        "smul", "off_h", "off_w", "tstep_h", "tstep_w", "sdiv",
                                        "ldy", "ldres", "relu", "dtype")] + \
                [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("n_active", C.c_void_p),
-                ("residual_mask", C.c_void_p), ("ld_residual_mask", C.c_int)]
+                ("residual_mask", C.c_void_p), ("ld_residual_mask", C.c_int),
+                ("n_taps", C.c_int), ("taps", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "eeseg_dropout": (_i, [_vp, _vp, _i64, _f, _u64, _vp, _i, _vp]),
     "eeseg_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "eeseg_add_inplace": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "eeseg_copy2d": (_i, [_vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "eeseg_colsum": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _i64, _vp]),
     "eeseg_upsample_bilinear_nchw": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_upsample_bilinear_nchw_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -38,6 +38,12 @@ struct ConvP {
     const int* n_active;      // device count of the leading images that are computed at all (NULL = all)
     const unsigned char* resmask;   // optional 1-bit mask of the residual (one byte per 16-byte chunk of a row, bn_apply_relu_mask)
     int ldmask;                     // bytes per mask row
+    // generalised taps (256-tile kernel only): the K loop walks n_gtaps (shift, source) pairs instead of an R x S grid -
+    // tap t reads source pixel (h + gdh[t], w + gdw[t]) of the [N,Hin,Win,Cin] tensor that starts goff[t] bytes behind x.
+    // One launch then sums several convolutions of different dilation into one output (the ASPP data-gradient).
+    int n_gtaps;
+    short gdh[32], gdw[32];
+    int goff[32];
 };
 
 // residual chunk `q` (8 bf16) AND-ed with mask byte `mb`: element e survives iff bit e is set
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     {
-        const int taps = p.R * p.S;
+        const int taps = p.n_gtaps ? p.n_gtaps : p.R * p.S;
         // DMA role: one wave-instruction = 8 rows x 128 B; per half tile a thread fetches rows rr and rr+64
         const int rr = wave * 8 + (lane >> 3);
         const int gchunk = (lane & 7) ^ ((rr >> 1) & 7);    // XOR swizzle on the SOURCE chunk (LDS image is lane-linear)
@@ -591,6 +597,14 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                 }
             }
             __syncthreads();
+            if (p.n_gtaps) {                   // generalised taps: one (h, w) range check per tap and row
+                for (int t = 0; t < p.n_gtaps; ++t) {
+                    const int dh = p.gdh[t], dw = p.gdw[t];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((unsigned)(hb[k] + dh) < (unsigned)p.Hin && (unsigned)(wb[k] + dw) < (unsigned)p.Win) vmask[k] |= 1u << t;
+                }
+            } else
             // tap (r, s) is visible from a row iff r is visible along h and s along w: R + S range checks per row
             {
                 unsigned hm[4] = {0u, 0u, 0u, 0u}, wm[4] = {0u, 0u, 0u, 0u};
@@ -645,8 +659,12 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         auto pop_tap = [&]() {
             cur_tap = rest ? __ffs(rest) - 1 : 0;
             rest &= rest - 1;
-            const int r = (cur_tap * rcpS) >> 16, s = cur_tap - r * p.S;
-            dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * 2;
+            if (p.n_gtaps) {
+                dtap = (p.gdh[cur_tap] * p.Win + p.gdw[cur_tap]) * p.Cin * 2 + p.goff[cur_tap];
+            } else {
+                const int r = (cur_tap * rcpS) >> 16, s = cur_tap - r * p.S;
+                dtap = ((r * p.tstep_h) * p.Win + s * p.tstep_w) * p.Cin * 2;
+            }
             upd = true;
         };
         if (p.tap_inner) {
@@ -1602,7 +1620,7 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     const int tiles = (int)((M + BIGT - 1) / BIGT) * p.n_tiles;
     const int cus = g_conv_big_cus;
     const int rounds = tiles / cus, rem = tiles % cus;
-    const int nk_max = p.R * p.S * (p.Cin / 64);
+    const int nk_max = (p.n_gtaps ? p.n_gtaps : p.R * p.S) * (p.Cin / 64);
     int ksplit = 1;
     if (rem > 0 && rem < g_conv_big_tail_min * cus / 256) {
         ksplit = cus / rem;
@@ -1798,6 +1816,24 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.tap_inner = g_conv_linear;
     p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.pointwise = 0;
     p.n_active = a->n_active;
+    p.n_gtaps = 0;
+    if (a->n_taps > 0) {      // generalised taps: R = 1, S = n_taps describe the weight tensor [Cout][n_taps][Cin]
+        EESEG_CHECK(a->taps && a->n_taps <= 32 && a->R == 1 && a->S == a->n_taps, EESEG_ERR_ARG,
+                    "conv_igemm: tap table needs taps != NULL, n_taps <= 32, R = 1, S = n_taps");
+        EESEG_CHECK(g_conv_pipe == 3 && a->dtype == EESEG_BF16 && a->sdiv == 1 && a->smul == 1 && a->Cout % BIGT == 0 &&
+                        a->Hin == a->Hout && a->Win == a->Wout && !a->stats,
+                    EESEG_ERR_ARG, "conv_igemm: a tap table runs on the 256-tile bf16 kernel only (Cout %% 256 == 0, stride 1)");
+        p.n_gtaps = a->n_taps;
+        for (int t = 0; t < a->n_taps; ++t) {
+            const long long off = a->taps[3 * t + 2];
+            EESEG_CHECK(off >= 0 && off % 16 == 0 && off + xbytes < (1ll << 31) && a->taps[3 * t] > -32768 &&
+                            a->taps[3 * t] < 32768 && a->taps[3 * t + 1] > -32768 && a->taps[3 * t + 1] < 32768,
+                        EESEG_ERR_ARG, "conv_igemm: bad tap table entry %d", t);
+            p.gdh[t] = (short)a->taps[3 * t]; p.gdw[t] = (short)a->taps[3 * t + 1]; p.goff[t] = (int)off;
+            if ((uint32_t)(off + xbytes) > p.xbytes) p.xbytes = (uint32_t)(off + xbytes);
+        }
+        p.off_h = 0; p.off_w = 0;
+    }
     p.resmask = a->residual_mask; p.ldmask = a->ld_residual_mask;
     EESEG_CHECK(!a->residual_mask || (a->residual && a->dtype == EESEG_BF16 && a->ld_residual_mask >= a->Cout / 8 &&
                                       a->Cout % 256 == 0 && a->sdiv == 1 && g_conv_pipe == 3),

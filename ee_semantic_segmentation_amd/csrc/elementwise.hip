@@ -1463,6 +1463,35 @@ extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_
     return EESEG_OK;
 }
 
+namespace {
+// rows x row_bytes (16-byte multiples) from a row pitch of src_ld to a row pitch of dst_ld bytes
+__global__ __launch_bounds__(256) void copy2d_kernel(const char* __restrict__ src, long long src_ld, char* __restrict__ dst,
+                                                     long long dst_ld, long long rows, int chunks) {
+    const long long total = rows * chunks;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        *reinterpret_cast<i32x4*>(dst + r * dst_ld + (long long)c * 16) =
+            *reinterpret_cast<const i32x4*>(src + r * src_ld + (long long)c * 16);
+    }
+}
+}  // namespace
+
+extern "C" int eeseg_copy2d(const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows,
+                            int64_t row_bytes, void* stream) {
+    EESEG_CHECK(src && dst && rows > 0 && row_bytes > 0, EESEG_ERR_ARG, "copy2d: bad argument");
+    EESEG_CHECK(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0 && dst_ld_bytes % 16 == 0 && src_ld_bytes >= row_bytes &&
+                    dst_ld_bytes >= row_bytes && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && row_bytes / 16 < (1ll << 31),
+                EESEG_ERR_ARG, "copy2d: rows, pitches and pointers must be 16-byte multiples / aligned");
+    const long long chunks = row_bytes / 16;
+    long long blocks = (rows * chunks + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                       (long long)src_ld_bytes, (char*)dst, (long long)dst_ld_bytes, (long long)rows, (int)chunks);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
 extern "C" int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream) {
     EESEG_CHECK(x && y && n > 0, EESEG_ERR_ARG, "add_inplace: bad argument");
     const int epc = 16 / eeseg_dtype_size(dtype);

@@ -39,6 +39,7 @@ class Config:
         self.accumulate = False              # arena mode: add to the stored gradients instead of overwriting
         self.step_counter = None             # device int64[1]; lets a captured graph draw fresh dropout masks
         self.on_unit_done = None             # callable(unit_id): gradient bucket scheduling (GradReducer)
+        self.merge_aspp_dgrad = __import__("os").environ.get("EESEG_MERGE_ASPP_DGRAD", "1") != "0"   # one data-gradient launch per ASPP head
         self.fuse_block_residual = __import__("os").environ.get("EESEG_FUSE_BLOCK_RESIDUAL", "1") != "0"   # identity blocks: dout * mask is added by conv1's data-gradient, not written by BN backward
         self.overlap_wgrad = False           # opt-in (measured +-0 with the 256-tile kernels): weight-gradient on a side stream, concurrent with the data-gradient:
         self._side = None                    # the two kernels fill each other's partially filled last block round
@@ -364,7 +365,8 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
     return y, (x, c, None, mi, count, relu, ss)
 
 
-def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False, dx_add=None):
+def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False, dx_add=None,
+                dc_out=None):
     """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
     parameter gradients are None in arena mode (written in place).  dx_add=(t, mask): the data-gradient adds
     t * mask (bit mask) in its epilogue - the masked block gradient of a bottleneck, never materialised."""
@@ -386,7 +388,7 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         sums = sums.clone() if pair is not None else sums
         _allreduce(cfg, sums)
     dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
-                              scale_shift=ss)
+                              scale_shift=ss, dx=dc_out)        # dc_out: the caller's buffer for the conv-output gradient
     gv = cfg.gview(conv.weight)
     if x_is_col:
         dw = K.conv_wgrad(x, dc, 1, 1)
@@ -668,11 +670,28 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
     dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
     grads_convs = []
     dx = dx_init if head.pre is None else None
-    for i in range(nb - 1):
-        seq = aspp.convs[i]
-        sl = dcat[..., i * mid:(i + 1) * mid]
-        dx, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], dx_accum=dx)
-        grads_convs += [dwi, dgi, dbi]
+    convs = [aspp.convs[i][0] for i in range(nb - 1)]
+    ntaps = sum(cv.kernel_size[0] * cv.kernel_size[1] for cv in convs)
+    merge = (cfg.merge_aspp_dgrad and dcat.is_cuda and all(cv.stride[0] == 1 for cv in convs) and
+             K.multi_dgrad_ok(dcat.dtype, cin, mid, ntaps))
+    if merge:
+        # ONE data-gradient launch for the 1x1 + atrous branches (generalised taps): dx is written once instead of being
+        # read-modify-written by every branch, and a 256 x 256 output tile pays one epilogue for all 28 taps
+        dcc = torch.empty((nb - 1, N, h, w, mid), dtype=dcat.dtype, device=dcat.device)
+        for i in range(nb - 1):
+            seq = aspp.convs[i]
+            sl = dcat[..., i * mid:(i + 1) * mid]
+            _, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], need_dx=False, dc_out=dcc[i])
+            grads_convs += [dwi, dgi, dbi]
+        wcat = K.concat_tap_weights([packed(cv, dcat.dtype)[1] for cv in convs])
+        dx = K.conv_dgrad_multi(dcc, wcat, [(cv.kernel_size[0], cv.padding[0], cv.dilation[0]) for cv in convs],
+                                accumulate_into=dx)
+    else:
+        for i in range(nb - 1):
+            seq = aspp.convs[i]
+            sl = dcat[..., i * mid:(i + 1) * mid]
+            dx, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], dx_accum=dx)
+            grads_convs += [dwi, dgi, dbi]
     pool = aspp.convs[nb - 1]
     dpv = K.sum_hw(dcat[..., (nb - 1) * mid:]).view(N, 1, 1, mid)
     dg_, _, dwp, dgp, dbp = conv_bn_bwd(cfg, states[nb - 1], dpv, pool[1], pool[2])

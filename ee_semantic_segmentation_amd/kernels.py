@@ -248,6 +248,75 @@ def conv_dgrad(dy, w_bwd, in_hw, stride=1, pad=0, dil=1, *, accumulate_into=None
     return dx
 
 
+def multi_dgrad_ok(dtype, cin, mid, ntaps):
+    """Can conv_dgrad_multi sum `ntaps` taps of data-gradients (dy channels = mid) into a cin-wide dx?"""
+    return (dtype == torch.bfloat16 and cin % 256 == 0 and mid % 64 == 0 and 0 < ntaps <= 32 and
+            lib().eeseg_get_option(1) == 3)
+
+
+def concat_tap_weights(w_bwds):
+    """[w_bwd_b: [Cin,R_b,S_b,Cout] (CRSK packed)] -> [Cin, sum R_b*S_b, Cout]: the taps of every conv side by side
+    (strided row copies, one launch per conv)."""
+    cin, co = w_bwds[0].shape[0], w_bwds[0].shape[3]
+    T = sum(w.shape[1] * w.shape[2] for w in w_bwds)
+    out = torch.empty((cin, T, co), dtype=w_bwds[0].dtype, device=w_bwds[0].device)
+    es = out.element_size()
+    t0 = 0
+    for w in w_bwds:
+        assert w.is_contiguous() and w.shape[0] == cin and w.shape[3] == co and w.dtype == out.dtype
+        tb = w.shape[1] * w.shape[2]
+        check(lib().eeseg_copy2d(_p(w), tb * co * es, C.c_void_p(out.data_ptr() + t0 * co * es), T * co * es, cin,
+                                 tb * co * es, _stream()), "eeseg_copy2d")
+        t0 += tb
+    return out
+
+
+def conv_dgrad_multi(dys, w_cat, geoms, *, accumulate_into=None):
+    """dx = sum_b dgrad_b(dys[b]): the data-gradients of several stride-1 convs of ONE input, in one launch.
+    dys [nb,N,H,W,Cout] contiguous (all convs: same output size as the input); w_cat = concat_tap_weights of their
+    w_bwd; geoms = [(k, pad, dil)] per conv.  Added into `accumulate_into` in place when given."""
+    _need_cuda(dys, w_cat)
+    nb, N, H, W, Cout = dys.shape
+    Cin, T, Cout2 = w_cat.shape
+    assert dys.is_contiguous() and w_cat.is_contiguous() and Cout2 == Cout and w_cat.dtype == dys.dtype and len(geoms) == nb
+    taps = []
+    for b, (k, pad, dil) in enumerate(geoms):
+        assert conv_out_size(H, k, 1, pad, dil) == H and conv_out_size(W, k, 1, pad, dil) == W
+        off = b * N * H * W * Cout * dys.element_size()
+        for r in range(k):
+            for s_ in range(k):
+                taps.append((pad - r * dil, pad - s_ * dil, off))      # the data-gradient's source pixel of tap (r, s)
+    assert len(taps) == T
+    tab = (C.c_int32 * (3 * T))(*[v for t in taps for v in t])
+    if accumulate_into is not None:
+        dx = accumulate_into
+        assert dx.shape == (N, H, W, Cin) and dx.dtype == dys.dtype
+        res = dx
+    else:
+        dx = torch.empty((N, H, W, Cin), dtype=dys.dtype, device=dys.device)
+        res = None
+    _, _, ld = rows_ld(dx)
+    a = ConvArgs()
+    a.x, a.w, a.y = dys.data_ptr(), w_cat.data_ptr(), dx.data_ptr()
+    a.scale = a.shift = a.stats = 0
+    a.residual = 0 if res is None else res.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cout, H, W, Cin, 1, T
+    a.smul, a.off_h, a.off_w, a.tstep_h, a.tstep_w, a.sdiv = 1, 0, 0, 1, 1, 1
+    a.ldy, a.ldres, a.relu, a.dtype = ld, (ld if res is not None else 0), 0, _dt(dys)
+    ws = _conv_ws(dys.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    a.n_active = 0
+    a.residual_mask, a.ld_residual_mask = 0, 0
+    a.n_taps, a.taps = T, C.cast(tab, C.c_void_p).value
+    ev = _prof_begin()
+    check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm (tap table)")
+    if ev is not None:
+        _prof_end(ev, "conv_big_kernel<bf16,256x256>", 2.0 * N * H * W * Cin * Cout * T,
+                  2.0 * (nb * N * H * W * Cout + Cin * T * Cout + N * H * W * Cin * (2 if res is not None else 1)),
+                  f"3x3 dgrad-multi {Cout}x{nb}->{Cin} T{T}")
+    return dx
+
+
 def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=False):
     """Returns dw fp32 KRSC [Cout,R,S,Cin]."""
     _need_cuda(x, dy)

@@ -104,6 +104,12 @@ typedef struct {
     int ld_residual_mask;         /* per 16-byte chunk of a residual row, bit e = element e (the ReLU mask eeseg_bn_apply_relu_mask
                                      writes), ld = bytes per mask row.  Lets the data-gradient of a bottleneck's first conv add the
                                      masked block gradient itself, so BatchNorm backward need not write it (bf16, Cout % 256 == 0). */
+    int n_taps;                   /* 0 = a regular R x S convolution.  > 0: GENERALISED taps (<= 32; bf16 256-tile kernel, stride 1, */
+    const int32_t* taps;          /* Cout % 256 == 0): HOST array [n_taps][3] = {dh, dw, byte offset}; tap t multiplies weight slice
+                                     w[co][t][:] (w = [Cout][n_taps][Cin], pass R = 1, S = n_taps) with source pixel (h + dh, w + dw) of the
+                                     [N,Hin,Win,Cin] tensor that starts `byte offset` behind x (zero outside the image).  One launch sums
+                                     convolutions of different dilation / different inputs into one output: the four data-gradients of an
+                                     ASPP head (torchvision ASPP: 1x1 + three atrous 3x3, from_deepv3_new.py:13,131) write dx once. */
 } eeseg_conv_args;
 int64_t eeseg_conv_workspace(void);
 int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */
@@ -226,6 +232,10 @@ int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, con
 int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, int64_t n, void* stream);
 /* y[i] += x[i] (gradient accumulation at residual joins) */
 int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream);
+/* strided row copy (16-byte multiples): dst[r][0:row_bytes] = src[r][0:row_bytes]; builds the tap-concatenated weights of
+ * a generalised-tap conv (eeseg_conv_args.taps) from the per-conv packed weights */
+int eeseg_copy2d(const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows, int64_t row_bytes,
+                 void* stream);
 /* per-column sum of a [rows][C] matrix -> out[C] fp32 (bias gradient) */
 int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* out, int dtype, void* workspace,
                  int64_t workspace_bytes, void* stream);

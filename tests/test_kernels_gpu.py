@@ -955,3 +955,42 @@ def test_identity_block_backward_with_fused_residual_is_bit_identical():
     assert torch.equal(outs[0][0], outs[1][0])            # the input gradient: same kernels, same arithmetic
     for a, b in zip(outs[0][1:], outs[1][1:]):            # weight gradients are summed with fp32 atomics: last-bit noise
         close(a, b, 1e-3, "parameter gradient")
+
+
+@pytest.mark.parametrize("shape,accumulate", [((2, 33, 31, 512, 256), False), ((1, 65, 65, 1024, 256), True)],
+                         ids=["2x33x31-512", "1x65x65-1024-acc"])
+def test_aspp_data_gradients_in_one_launch(shape, accumulate):
+    """conv_dgrad_multi (eeseg_conv_args.taps: generalised taps on the 256-tile kernel): the data-gradients of a 1x1 and
+    three atrous 3x3 convs of ONE input (dilations 12 / 24 / 36: whole taps fall outside the map and are skipped),
+    28 taps in one launch, against torch autograd in fp32 on the same bf16 values."""
+    N, H, W, Cin, mid = shape
+    g = torch.Generator().manual_seed(12)
+    geoms = [(1, 0, 1), (3, 12, 12), (3, 24, 24), (3, 36, 36)]
+    x = torch.zeros(N, Cin, H, W, requires_grad=True)
+    ws = [rnd(torch.bfloat16, mid, Cin, k, k, seed=20 + i, scale=(Cin * k * k) ** -0.5).requires_grad_(False)
+          for i, (k, p, d) in enumerate(geoms)]
+    dys = [rnd(torch.bfloat16, N, mid, H, W, seed=30 + i) for i in range(4)]
+    tot = sum((F.conv2d(x, w, padding=p, dilation=d) * dy).sum() for w, dy, (k, p, d) in zip(ws, dys, geoms))
+    tot.backward()
+    want = x.grad
+    base = rnd(torch.bfloat16, N, Cin, H, W, seed=40) if accumulate else None
+    if accumulate:
+        want = want + base
+    wbs = [K.pack_weight(w.to(DEV), torch.bfloat16)[1] for w in ws]
+    wcat = K.concat_tap_weights(wbs)
+    assert wcat.shape == (Cin, 28, mid)
+    t0 = 0
+    for wb in wbs:                                         # the taps of every conv side by side, bit for bit
+        tb = wb.shape[1] * wb.shape[2]
+        assert torch.equal(wcat[:, t0:t0 + tb], wb.reshape(Cin, tb, mid))
+        t0 += tb
+    dcc = torch.stack([nhwc(dy).to(DEV, torch.bfloat16) for dy in dys]).contiguous()
+    acc = nhwc(base).to(DEV, torch.bfloat16) if accumulate else None
+    dx = K.conv_dgrad_multi(dcc, wcat, geoms, accumulate_into=acc)
+    close(nchw(dx), want, tol(torch.bfloat16), "merged ASPP data-gradient")
+    # and against the four separate launches it replaces (those round to bf16 after every branch)
+    sep = None
+    for wb, dy, (k, p, d) in zip(wbs, dcc, geoms):
+        sep = K.conv_dgrad(dy, wb, (H, W), 1, p, d, accumulate_into=sep)
+    if not accumulate:
+        close(dx, sep, 2.5e-2, "merged vs separate launches")
