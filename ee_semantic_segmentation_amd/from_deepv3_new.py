@@ -79,23 +79,39 @@ def model_macs(net, H, W):
 class my_branch(DeepLabHead):
     """from_deepv3_new.py:15-39: a DeepLabHead with its own atrous rates / width and, with `bottleneck`, a leading
     1x1 conv (+bias, no BN, no activation) that narrows the features first.  Child indices (= state_dict keys) are
-    the reference's: [0: bottleneck conv,] ASPP, 3x3 conv, BN, ReLU, 1x1 classifier."""
+    the reference's: [0: bottleneck conv,] ASPP, 3x3 conv, BN, ReLU, 1x1 classifier.  Any bottleneck width is
+    accepted, like the reference: a width that is not a multiple of 64 is stored zero-padded (nn_modules.Conv2d),
+    state_dict shapes and the MAC count stay the true ones."""
 
     def __init__(self, nin_channels, num_classes, atrous_rates, nout_channels, bottleneck=None, cfg=None, **kw):
         if not bottleneck:
             super().__init__(nin_channels, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg)
             return
-        if bottleneck % 64:
-            raise ValueError("my_branch: bottleneck width must be a multiple of 64 channels (K tile of the conv kernels)")
-        super().__init__(bottleneck, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg)
+        super().__init__(bottleneck, num_classes, tuple(atrous_rates), nout_channels, cfg=cfg, pad_in_to=64)
         rest = list(self.children())
-        pre = Conv2d(nin_channels, bottleneck, 1, bias=True)
+        pre = Conv2d(nin_channels, bottleneck, 1, bias=True, pad_out_to=64)
         pre.__dict__["_eeseg_role"] = "pre"
         for k in list(self._modules):
             del self._modules[k]
         for i, m in enumerate([pre] + rest):
             self.add_module(str(i), m)
         self._off = 1
+        self._padded = [m for m in self.modules() if isinstance(m, Conv2d) and m.channel_padded]
+
+    def _keep_padding_zero(self):
+        # a training forward re-asserts the zero padding, so an in-place initialiser applied from outside
+        # (net.apply(init_fn)) cannot turn the padding channels into real ones
+        if self.training and torch.is_grad_enabled():
+            for m in getattr(self, "_padded", ()):
+                m.zero_channel_padding_()
+
+    def forward(self, x):
+        self._keep_padding_zero()
+        return super().forward(x)
+
+    def forward_fork(self, x):
+        self._keep_padding_zero()
+        return super().forward_fork(x)
 
 
 # ------------------------------------------------------------ exit logits -----

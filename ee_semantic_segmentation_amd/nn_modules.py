@@ -17,28 +17,70 @@ from . import engine as E
 # ---------------------------------------------------------------- holders ----
 class Conv2d(nn.Module):
     """Parameter holder with torch.nn.Conv2d's attributes; weight is stored
-    channels_last (= KRSC, the kernels' layout) so weight gradients need no copy."""
+    channels_last (= KRSC, the kernels' layout) so weight gradients need no copy.
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False):
+    ``pad_to``: the conv kernels move K in 128-byte steps, so channel counts that are not a multiple of 64 are
+    STORED zero-padded up to one (``weight``/``bias`` hold the padded tensors, the padding rows/columns are exact
+    zeros and stay zero under SGD: their activations and gradients are 0).  ``in_channels``/``out_channels``, the
+    default initialisation, the MAC counter and ``state_dict`` (save and load) keep the true sizes, i.e. the
+    reference's (my_branch(bottleneck=...) accepts any width, from_deepv3_new.py:23-24)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False, pad_in_to=1, pad_out_to=1):
         super().__init__()
         self.in_channels, self.out_channels = cin, cout
         self.kernel_size, self.stride = (k, k), (stride, stride)
         self.padding, self.dilation = (padding, padding), (dilation, dilation)
-        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        self.cin_stored = -(-cin // pad_in_to) * pad_in_to
+        self.cout_stored = -(-cout // pad_out_to) * pad_out_to
+        w = torch.empty(self.cout_stored, self.cin_stored, k, k).contiguous(memory_format=torch.channels_last)
         self.weight = nn.Parameter(w)
-        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.bias = nn.Parameter(torch.empty(self.cout_stored)) if bias else None
         self.reset_parameters()
 
+    @property
+    def channel_padded(self):
+        return self.cin_stored != self.in_channels or self.cout_stored != self.out_channels
+
     def reset_parameters(self):   # torch.nn.Conv2d default init (heads keep it: SURVEY F7)
-        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
-        if self.bias is not None:
-            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
-            bound = 1 / fan_in ** 0.5
-            nn.init.uniform_(self.bias, -bound, bound)
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        with torch.no_grad():
+            bound = (6.0 / ((1 + 5) * fan_in)) ** 0.5            # kaiming_uniform_(a=sqrt(5)) on the TRUE fan-in
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-1 / fan_in ** 0.5, 1 / fan_in ** 0.5)
+        self.zero_channel_padding_()
+
+    @torch.no_grad()
+    def zero_channel_padding_(self):
+        """Restore the invariant after anything wrote the stored tensors in place (an external init)."""
+        if self.cout_stored != self.out_channels:
+            self.weight[self.out_channels:].zero_()
+            if self.bias is not None:
+                self.bias[self.out_channels:].zero_()
+        if self.cin_stored != self.in_channels:
+            self.weight[:, self.in_channels:].zero_()
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.channel_padded:                                # the reference's shapes
+            destination[prefix + "weight"] = destination[prefix + "weight"][:self.out_channels, :self.in_channels]
+            if self.bias is not None:
+                destination[prefix + "bias"] = destination[prefix + "bias"][:self.out_channels]
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        if self.channel_padded:
+            for name, true in (("weight", (self.out_channels, self.in_channels)), ("bias", (self.out_channels,))):
+                t = state_dict.get(prefix + name)
+                if t is not None and tuple(t.shape[:len(true)]) == true:
+                    full = torch.zeros(getattr(self, name).shape, dtype=t.dtype, device=t.device)
+                    full[tuple(slice(0, n) for n in true)] = t
+                    state_dict[prefix + name] = full
+        super()._load_from_state_dict(state_dict, prefix, *args)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
-                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}")
+                f"padding={self.padding}, dilation={self.dilation}, bias={self.bias is not None}"
+                + (f", stored as {self.cin_stored}->{self.cout_stored}" if self.channel_padded else ""))
 
     def forward(self, x):
         raise RuntimeError("Conv2d is fused by its parent block (stem / Bottleneck / DeepLabHead)")
@@ -183,22 +225,23 @@ class Bottleneck(nn.Module):
 
 # ------------------------------------------------------------------ head -----
 class ASPPConv(nn.Sequential):
-    def __init__(self, cin, cout, dilation):
-        super().__init__(Conv2d(cin, cout, 3, padding=dilation, dilation=dilation), BatchNorm2d(cout), ReLU())
+    def __init__(self, cin, cout, dilation, pad_in_to=1):
+        super().__init__(Conv2d(cin, cout, 3, padding=dilation, dilation=dilation, pad_in_to=pad_in_to),
+                         BatchNorm2d(cout), ReLU())
 
 
 class ASPPPooling(nn.Sequential):
-    def __init__(self, cin, cout):
-        super().__init__(AdaptiveAvgPool2d(1), Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU())
+    def __init__(self, cin, cout, pad_in_to=1):
+        super().__init__(AdaptiveAvgPool2d(1), Conv2d(cin, cout, 1, pad_in_to=pad_in_to), BatchNorm2d(cout), ReLU())
 
 
 class ASPP(nn.Module):
-    def __init__(self, cin, atrous_rates=(12, 24, 36), cout=256):
+    def __init__(self, cin, atrous_rates=(12, 24, 36), cout=256, pad_in_to=1):
         super().__init__()
-        mods = [nn.Sequential(Conv2d(cin, cout, 1), BatchNorm2d(cout), ReLU())]
+        mods = [nn.Sequential(Conv2d(cin, cout, 1, pad_in_to=pad_in_to), BatchNorm2d(cout), ReLU())]
         for r in atrous_rates:
-            mods.append(ASPPConv(cin, cout, r))
-        mods.append(ASPPPooling(cin, cout))
+            mods.append(ASPPConv(cin, cout, r, pad_in_to))
+        mods.append(ASPPPooling(cin, cout, pad_in_to))
         self.convs = nn.ModuleList(mods)
         self.project = nn.Sequential(Conv2d(len(mods) * cout, cout, 1), BatchNorm2d(cout), ReLU(), Dropout(0.5))
 
@@ -245,10 +288,10 @@ class DeepLabHead(nn.Sequential):
     """torchvision DeepLabHead (Appendix A.2): ASPP -> 3x3 -> BN -> ReLU -> 1x1(+bias).
     Returns low-resolution logits [N,h,w,32] fp32 (first `num_classes` channels valid)."""
 
-    def __init__(self, cin, num_classes, atrous_rates=(12, 24, 36), mid=256, cfg=None):
+    def __init__(self, cin, num_classes, atrous_rates=(12, 24, 36), mid=256, cfg=None, pad_in_to=1):
         if num_classes > E.CPAD:
             raise ValueError(f"at most {E.CPAD} classes are supported by the fused loss kernels")
-        super().__init__(ASPP(cin, atrous_rates, mid), Conv2d(mid, mid, 3, padding=1), BatchNorm2d(mid), ReLU(),
+        super().__init__(ASPP(cin, atrous_rates, mid, pad_in_to), Conv2d(mid, mid, 3, padding=1), BatchNorm2d(mid), ReLU(),
                          Conv2d(mid, num_classes, 1, bias=True))
         self.__dict__["cfg"] = cfg
         self.num_classes = num_classes
