@@ -44,7 +44,25 @@ struct ConvP {
     int n_gtaps;
     short gdh[32], gdw[32];
     int goff[32];
+    // 256-tile kernel, tile order: tiles below cg_limit are walked in groups of 32 = cg cout tiles x (32 / cg) pixel tiles
+    // (0 = cout tiles fastest over ALL n_tiles): the 32 CUs of an XCD then share cg weight tiles instead of n_tiles
+    int cg, cg_limit;
 };
+
+// tile index -> (cout tile, pixel tile) of the 256-tile kernel and its fix-up
+__device__ __forceinline__ void big_tile_coords(const ConvP& p, int tile, int& nt, int& mt) {
+    if (tile < p.cg_limit) {
+        const int blk = tile >> 5, in = tile & 31;
+        const int ngrp = p.n_tiles / p.cg;
+        const int pg = blk / ngrp, cgi = blk - pg * ngrp;
+        const int c = in % p.cg;
+        nt = cgi * p.cg + c;
+        mt = pg * (32 / p.cg) + in / p.cg;
+    } else {
+        nt = tile % p.n_tiles;
+        mt = tile / p.n_tiles;
+    }
+}
 
 // residual chunk `q` (8 bf16) AND-ed with mask byte `mb`: element e survives iff bit e is set
 __device__ __forceinline__ i32x4 mask_chunk_bf16(i32x4 q, unsigned mb) {
@@ -528,7 +546,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
     const int tile_local = split_blk ? unit / nsplit : unit;
     const int split = split_blk ? unit - tile_local * nsplit : 0;
     const int tile = (split_blk || MODE == 0) ? p.tile_begin + tile_local : tile_local;
-    const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
+    int nt, mt;
+    big_tile_coords(p, tile, nt, mt);
     const int m0 = mt * BIGT, n0 = nt * BIGT;
     EESEG_ACTIVE_EXIT(m0);
     const int wc = wave & 3, wp = wave >> 2;
@@ -961,7 +980,8 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
     const int tile_local = blockIdx.x >> 3, slice = blockIdx.x & 7;
     const int wp = slice >> 2, j = slice & 3;
     const int tile = p.tile_begin + tile_local;
-    const int nt = tile % p.n_tiles, mt = tile / p.n_tiles;
+    int nt, mt;
+    big_tile_coords(p, tile, nt, mt);
     const int m0 = mt * BIGT + wp * 128 + j * SL, n0 = nt * BIGT;
     EESEG_ACTIVE_EXIT(mt * BIGT);            // same decision as the blocks that would have filled this tile's slabs
     const int fr = lane & 31, fh = lane >> 5;
@@ -1614,12 +1634,20 @@ int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K rang
 int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
+int g_conv_big_cg = 0;           // EESEG_OPT_CONV_COUT_GROUP: cout tiles an XCD works on at a time when a layer has more (0 = all; measured neutral: the merged ASPP data-gradient 3.18-3.27 ms for 0/1/2/4/8)
 
 // launch plan for the 256x256 kernel: full rounds of one tile per available CU, then the remainder split along K
 int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long workspace_bytes) {
-    const int tiles = (int)((M + BIGT - 1) / BIGT) * p.n_tiles;
+    const int mtiles = (int)((M + BIGT - 1) / BIGT);
+    const int tiles = mtiles * p.n_tiles;
     const int cus = g_conv_big_cus;
     const int rounds = tiles / cus, rem = tiles % cus;
+    p.cg = 1; p.cg_limit = 0;
+    if (g_conv_big_cg > 0 && p.n_tiles > g_conv_big_cg && p.n_tiles % g_conv_big_cg == 0) {
+        const int pgs = 32 / g_conv_big_cg;                       // pixel tiles per group
+        p.cg = g_conv_big_cg;
+        p.cg_limit = mtiles / pgs * pgs * p.n_tiles;              // the ragged last pixel tiles keep the plain order
+    }
     const int nk_max = (p.n_gtaps ? p.n_gtaps : p.R * p.S) * (p.Cin / 64);
     int ksplit = 1;
     if (rem > 0 && rem < g_conv_big_tail_min * cus / 256) {
@@ -1686,6 +1714,10 @@ extern int g_colreduce_blocks;
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
         g_conv_pipe = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_COUT_GROUP && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) {
+        g_conv_big_cg = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_CONV_AUTO_NARROW && (value == 0 || value == 1)) {
@@ -1765,6 +1797,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_PW_MAX_K: return g_conv_pw_max_k;
         case EESEG_OPT_CONV_PWS: return g_conv_pws;
         case EESEG_OPT_CONV_PW_ALL: return g_conv_pw_all;
+        case EESEG_OPT_CONV_COUT_GROUP: return g_conv_big_cg;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;

@@ -994,3 +994,26 @@ def test_aspp_data_gradients_in_one_launch(shape, accumulate):
         sep = K.conv_dgrad(dy, wb, (H, W), 1, p, d, accumulate_into=sep)
     if not accumulate:
         close(dx, sep, 2.5e-2, "merged vs separate launches")
+
+
+def test_conv_256_tile_cout_group_order():
+    """EESEG_OPT_CONV_COUT_GROUP: layers with more cout tiles than the group walk their tiles in blocks of
+    (group cout tiles) x (32 / group pixel tiles) - only the ORDER of the tiles changes, so every setting gives the same
+    bits (full rounds, K-split tail + fix-up, ragged last pixel tiles), and they match torch."""
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W, Cin, Cout = 4, 65, 65, 64, 2048          # 67 pixel tiles x 8 cout tiles = 536 tiles: 2 rounds + a split tail
+    x = rnd(torch.bfloat16, N, Cin, H, W, seed=3)
+    w = rnd(torch.bfloat16, Cout, Cin, 3, 3, seed=4, scale=(Cin * 9) ** -0.5)
+    want = F.conv2d(x.float(), w.float(), padding=2, dilation=2)
+    wf, _ = K.pack_weight(w.to(DEV), torch.bfloat16)
+    xd = nhwc(x).to(DEV, torch.bfloat16)
+    outs = {}
+    try:
+        for cg in (0, 1, 2, 4, 8):
+            assert lib().eeseg_set_option(16, cg) == 0
+            outs[cg] = K.conv_fwd(xd, wf, 1, 2, 2)[0].clone()
+    finally:
+        lib().eeseg_set_option(16, 0)
+    close(nchw(outs[4]), want, tol(torch.bfloat16), "cout-grouped tile order vs torch")
+    for cg, y in outs.items():
+        assert torch.equal(y, outs[0]), cg
