@@ -45,6 +45,7 @@ SIGNATURES = {
     "eeseg_version": (_i, []),
     "eeseg_set_option": (_i, [_i, _i]),
     "eeseg_get_option": (_i, [_i]),
+    "eeseg_last_kernel": (_i, [_i]),
     "eeseg_set_ew_grid_cap": (_i, [_i]),
     "eeseg_set_wgrad_target_blocks": (_i, [_i]),
     "eeseg_set_wgrad_big": (_i, [_i]),

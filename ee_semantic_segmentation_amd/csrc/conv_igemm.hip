@@ -1628,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
 int g_conv_pw_all = 0;        // EESEG_OPT_CONV_PW_ALL: 1 = every eligible pointwise layer on conv_pw_kernel, not only the output-heavy ones
 int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwise layers on the weight-stationary kernel
 
+int g_last_conv_kernel = 0;    // eeseg_last_kernel(0): which kernel the last eeseg_conv_igemm call launched (EESEG_KERNEL_*)
 int g_conv_pw_max_k = 1280;   // EESEG_OPT_CONV_PW_MAX_K: pointwise bf16 layers with Cin <= this use conv_pw_kernel (0 = never)
 
 int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K range of a split tail tile holds at least
@@ -1710,6 +1711,14 @@ extern int g_ce_span;     // loss.hip
 extern int g_bn_reverse;  // elementwise.hip
 extern int g_bn_rows;
 extern int g_colreduce_blocks;
+
+extern int g_last_wgrad_kernel;   // conv_wgrad.hip
+
+extern "C" int eeseg_last_kernel(int which) {
+    if (which == 0) return g_last_conv_kernel;
+    if (which == 1) return g_last_wgrad_kernel;
+    return EESEG_ERR_ARG;
+}
 
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
@@ -1896,6 +1905,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
             hipLaunchKernelGGL(conv_pws_kernel, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
+            g_last_conv_kernel = EESEG_KERNEL_CONV_PWS;
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }
@@ -1905,10 +1915,12 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
             hipLaunchKernelGGL(conv_pw_kernel, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(256), 0, st, p);
+            g_last_conv_kernel = EESEG_KERNEL_CONV_PW;
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }
         p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
+        g_last_conv_kernel = EESEG_KERNEL_CONV_BIG;
         return launch_big(p, M, st, a->workspace, a->workspace_bytes);
     }
     // 128x64 tiles for thin outputs, and whenever the 128x128 grid would fill less than ~85 % of the
@@ -1916,6 +1928,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     const long long wide_blocks = ((M + BM - 1) / BM) * ((a->Cout + 127) / 128);
     const bool narrow = a->Cout <= g_conv_narrow_max || (g_conv_auto_narrow && wide_blocks < 448 && a->Cout > 64);
     p.n_tiles = narrow ? (a->Cout + 63) / 64 : (a->Cout + 127) / 128;
+    g_last_conv_kernel = narrow ? EESEG_KERNEL_CONV_IGEMM_64 : EESEG_KERNEL_CONV_IGEMM_128;
     if (a->dtype == EESEG_BF16) return narrow ? launch<bf16_t, 64>(p, st) : launch<bf16_t, 128>(p, st);
     return narrow ? launch<float, 64>(p, st) : launch<float, 128>(p, st);
 }

@@ -9,6 +9,8 @@
 //   64x64; split-K over pixel ranges, fp32 atomics into dW (KRSC, fp32).
 #include "eeseg_common.h"
 
+int g_last_wgrad_kernel = 0;        // eeseg_last_kernel(1) (conv_igemm.hip)
+
 namespace {
 
 struct WgP {
@@ -824,6 +826,7 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             const long long need = tiles * (splits + (G > 1 ? G : 0)) * 65536ll * 4;
             p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
                           ? reinterpret_cast<float*>(a->workspace) : nullptr;
+            g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_BIG;
             if (p.q64 == 0)
                 hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
             else
@@ -862,6 +865,7 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     p.splits = (int)splits; p.chunk = (int)chunk;
     const long long grid = tiles * splits;
     EESEG_CHECK(grid < (1ll << 31), EESEG_ERR_TOO_LARGE, "conv_wgrad: grid too large");
+    g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_128;
     if (a->dtype == EESEG_BF16)
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else

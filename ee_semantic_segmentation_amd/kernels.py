@@ -177,10 +177,10 @@ def _conv_call(x, w, y, N, Hin, Win, Cin, Hout, Wout, Cout, R, S, smul, off, tst
     check(lib().eeseg_conv_igemm(C.byref(a), _stream()), "eeseg_conv_igemm")
     if ev is not None:
         px = N * (Hin * Win if sdiv > 1 else Hout * Wout)      # algorithmic MACs (padding taps included)
-        if a.dtype == BF16 and sdiv == 1 and Cout % 256 == 0 and lib().eeseg_get_option(1) == 3:
-            fam = "conv_big_kernel<bf16,256x256>"      # one call = full rounds (+ K-split tail + fix-up) launches
-        else:
-            fam = f"conv_igemm_kernel<{'bf16' if a.dtype == BF16 else 'f32'},{64 if Cout <= 64 else 128}>"
+        dt = "bf16" if a.dtype == BF16 else "f32"
+        fam = {1: f"conv_igemm_kernel<{dt},128>", 2: f"conv_igemm_kernel<{dt},64>",
+               3: "conv_big_kernel<bf16,256x256>",     # one call = full rounds (+ K-split tail + fix-up) launches
+               4: "conv_pw_kernel", 5: "conv_pws_kernel"}[lib().eeseg_last_kernel(0)]    # the kernel the library chose
         es = 2 if a.dtype == BF16 else 4       # algorithmic bytes: every operand once
         _prof_end(ev, fam, 2.0 * px * Cout * Cin * R * S,
                   float(es) * (N * Hin * Win * Cin + Cout * R * S * Cin + N * Hout * Wout * Cout),
@@ -338,8 +338,9 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
     if ev is not None:
         es = 2 if a.dtype == BF16 else 4
-        _prof_end(ev, f"conv_wgrad_kernel<{'bf16' if a.dtype == BF16 else 'f32'}>",
-                  2.0 * N * Ho * Wo * Cout * Cin * R * S,
+        fam = "conv_wgrad_big_kernel" if lib().eeseg_last_kernel(1) == 7 else \
+            f"conv_wgrad_kernel<{'bf16' if a.dtype == BF16 else 'f32'}>"
+        _prof_end(ev, fam, 2.0 * N * Ho * Wo * Cout * Cin * R * S,
                   float(es) * (N * H * W * Cin + N * Ho * Wo * Cout) + 4.0 * Cout * R * S * Cin,
                   f"{R}x{S} wgrad {Cin}->{Cout} d{dil}")
     return out

@@ -58,6 +58,12 @@ enum { EESEG_OPT_CONV_COUT_GROUP = 16 /* 256x256 conv kernel, layers with more c
                                   measured 3% slower end to end on MI355X: the Infinity Cache absorbs the re-reads) */ };
 int eeseg_set_option(int key, int value);
 int eeseg_get_option(int key);   /* current value, or a negative error code */
+/* Which kernel the last eeseg_conv_igemm (which = 0) / eeseg_conv_wgrad (which = 1) call of this process launched - host-side
+ * state for measurement code that attributes a timed call to a kernel (bench.py's per-kernel roofline); 0 = none yet. */
+enum { EESEG_KERNEL_CONV_IGEMM_128 = 1, EESEG_KERNEL_CONV_IGEMM_64 = 2, EESEG_KERNEL_CONV_BIG = 3 /* 256x256 tile (+ K-split tail, fix-up) */,
+       EESEG_KERNEL_CONV_PW = 4 /* 128x256 pointwise */, EESEG_KERNEL_CONV_PWS = 5 /* weight-stationary pointwise */,
+       EESEG_KERNEL_WGRAD_128 = 6, EESEG_KERNEL_WGRAD_BIG = 7 };
+int eeseg_last_kernel(int which);
 /* upper bound on the grid of the column-fixed BatchNorm elementwise kernels (tuning) */
 int eeseg_set_ew_grid_cap(int blocks);
 /* split-K sizing of the 128x128-tile weight-gradient kernel: number of blocks (tiles x pixel splits) aimed at; 0 (default) =
