@@ -816,7 +816,9 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             const double blocks = (double)(tiles * splits);
             const double rounds = (double)((tiles * splits + T - 1) / T);
             const double big_us = rounds * (double)(chunk / 64) * 1.6 + 7.5 + 0.2 * blocks;
-            take_big = big_us <= alt.us;
+            // the 128-tile estimate is optimistic for few-tile layers (measured at 32 x 65 x 65: 1x1 1024->256 model 111 us, kernel
+            // 147 us, against 114 us for the 256-tile kernel; 3x3 256->256 model 230, kernel 257): it has to win clearly
+            take_big = big_us <= alt.us * 1.3;
         }
         if (g_wgrad_big == 2 || take_big) {
             // second reduce level when tiles x 8 blocks alone could not pull the slabs at the memory rate
