@@ -634,6 +634,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     if (!any) return;
 
     // ---- epilogue B: fp32 atomics into dW[co][tap][ci] -------------------------
+    // (the K splits of a tile finish together and add in the same order; walking the accumulator groups in eight rotated orders
+    // per split changed nothing, 117-531 us per call within 1 %: the adds are bound by the atomic rate, not by address conflicts)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll

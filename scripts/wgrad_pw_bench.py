@@ -22,7 +22,7 @@ def timeit(fn, iters=10):
         best = min(best, e0.elapsed_time(e1) / iters * 1e3)
     return best
 
-for H, Cin, Cout, k in ((65, 1024, 256, 1), (65, 256, 1024, 1), (65, 512, 2048, 1), (65, 2048, 512, 1), (65, 256, 256, 3), (65, 512, 512, 3)):
+for H, Cin, Cout, k in ((65, 1024, 256, 1), (65, 256, 1024, 1), (65, 512, 2048, 1), (65, 2048, 512, 1), (65, 256, 256, 3), (65, 512, 512, 3), (65, 2048, 256, 3)):
     x = (torch.randn(B, H, H, Cin, device=dev) * 0.1).bfloat16()
     dy = (torch.randn(B, H, H, Cout, device=dev) * 0.1).bfloat16()
     pad = dil = 2 if k == 3 else 0
