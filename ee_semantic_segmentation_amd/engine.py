@@ -45,6 +45,10 @@ class Config:
         self._side = None                    # the two kernels fill each other's partially filled last block round
         self._side_busy = False
         self._side_keep = []                 # tensors the side stream still reads (freed after the join)
+        # SyncBN backward: the weight gradient of layer L is held back and issued right after layer L-1's statistics
+        # all-reduce has been launched, so it runs while that (latency-bound) collective is in flight
+        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "1") != "0"
+        self._deferred = None
 
     def world(self):
         """Number of ranks BatchNorm statistics are reduced over (1 = local BN).  With
@@ -86,6 +90,25 @@ class Config:
             dist.all_reduce(t, group=self.group)
         return t
 
+    def all_reduce_begin(self, t):
+        """Launch the in-place sum of `t`; -> handle for all_reduce_end.  Kernels issued on the current stream between
+        the two calls run beside the collective (RCCL's own stream; parallel branches of a captured graph)."""
+        if self.collective is not None:
+            self.collective(t, self.group)
+            return None
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
+    @staticmethod
+    def all_reduce_end(work):
+        if work is not None:
+            work.wait()                      # stream-level: the current stream waits for the collective
+
+    def run_deferred(self):
+        """Issue the weight gradient that conv_bn_bwd held back (no-op when there is none)."""
+        fn, self._deferred = self._deferred, None
+        if fn is not None:
+            fn()
+
     def next_seed(self):
         self._drop_calls += 1
         return (self.dropout_seed * 0x9E3779B97F4A7C15 + self._drop_calls) & (2 ** 63 - 1)
@@ -116,6 +139,7 @@ class Config:
         return None if self.arena is None else self.arena.kernel_view.get(param)
 
     def unit_done(self, module):
+        self.run_deferred()                  # the unit's last weight gradient
         if self.overlap_wgrad == 2 and self.on_unit_done is None:
             return                           # nobody consumes the gradients before the optimizer step: join there
         self.join_side()                     # the unit's weight gradients are complete from here on
@@ -386,7 +410,9 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
         sums = sums.clone() if pair is not None else sums
-        _allreduce(cfg, sums)
+        work = cfg.all_reduce_begin(sums)
+        cfg.run_deferred()                   # the layer above's weight gradient fills the collective's latency
+        cfg.all_reduce_end(work)
     dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
                               scale_shift=ss, dx=dc_out)        # dc_out: the caller's buffer for the conv-output gradient
     gv = cfg.gview(conv.weight)
@@ -438,6 +464,15 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         cfg._side_keep.append((x, dc, dwp))
         _, wb = packed(conv, dc.dtype)
         dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)
+    elif gv is not None and cfg.defer_wgrad and cfg.sync_active() and not frozen:
+        # arena mode under SyncBN: data-gradient now, weight gradient (written in place, nothing to return) when the
+        # next layer's all-reduce is in flight - at the latest when the unit ends (Config.unit_done)
+        cfg.run_deferred()
+        if need_dx:
+            _, wb = packed(conv, dc.dtype)
+            dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)
+        cfg._deferred = wgrad                # the closure keeps x and dc alive
+        dwp = None
     else:
         dwp = wgrad()
         if need_dx:

@@ -212,6 +212,7 @@ class GraphedTrainStep:
         loss = self.criterion(out, y)
         self.opt.zero_grad(set_to_none=True)
         loss.mean().backward()
+        self.net.cfg.run_deferred()
         self.net.cfg.join_side()
         if self.reducer is not None:
             self.reducer.finish()
