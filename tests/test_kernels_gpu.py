@@ -1017,3 +1017,47 @@ def test_conv_256_tile_cout_group_order():
     close(nchw(outs[4]), want, tol(torch.bfloat16), "cout-grouped tile order vs torch")
     for cg, y in outs.items():
         assert torch.equal(y, outs[0]), cg
+
+
+@pytest.mark.parametrize("case", ["3x3-stats", "1x1-residual-relu", "atrous-tail"])
+def test_conv_256_tile_mfma_16x16x32(case):
+    """EESEG_OPT_CONV_MFMA16: the 256-tile kernel built on v_mfma_f32_16x16x32_bf16 (four 16x16 accumulators per 32x32
+    sub-block, other lane -> (cout, pixel) map in the epilogue, the K-split slabs and the fix-up) against torch and against
+    the 32x32x16 build: whole tiles, a K-split tail + fix-up, BN partial sums, residual + ReLU."""
+    from ee_semantic_segmentation_amd._lib import lib
+    if case == "3x3-stats":
+        N, H, W, Cin, Cout, k, pad, dil, res, relu, stats = 5, 65, 65, 128, 256, 3, 2, 2, False, False, True
+    elif case == "1x1-residual-relu":
+        N, H, W, Cin, Cout, k, pad, dil, res, relu, stats = 17, 65, 65, 1024, 256, 1, 0, 1, True, True, False
+    else:
+        N, H, W, Cin, Cout, k, pad, dil, res, relu, stats = 2, 33, 33, 256, 512, 3, 12, 12, False, False, True
+    x = rnd(torch.bfloat16, N, Cin, H, W, seed=5)
+    w = rnd(torch.bfloat16, Cout, Cin, k, k, seed=6, scale=(Cin * k * k) ** -0.5)
+    r = rnd(torch.bfloat16, N, Cout, H, W, seed=7) if res else None
+    want = F.conv2d(x.float(), w.float(), padding=pad, dilation=dil)
+    raw = want.bfloat16().float()
+    if res:
+        want = want.bfloat16().float() + r.float()
+    if relu:
+        want = want.clamp_min(0)
+    wf, _ = K.pack_weight(w.to(DEV), torch.bfloat16)
+    xd = nhwc(x).to(DEV, torch.bfloat16)
+    rd = nhwc(r).to(DEV, torch.bfloat16) if res else None
+    outs = {}
+    try:
+        lib().eeseg_set_option(13, 0)                  # keep pointwise layers off the 128x256 kernels for this comparison
+        for m16 in (0, 1):
+            assert lib().eeseg_set_option(17, m16) == 0
+            y, part = K.conv_fwd(xd, wf, 1, pad, dil, want_stats=stats, residual=rd, relu=relu)
+            assert lib().eeseg_last_kernel(0) == 3                      # the 256-tile kernel ran
+            outs[m16] = (y.clone(), None if part is None else K.reduce_partials(part).clone())
+    finally:
+        lib().eeseg_set_option(17, 1)
+        lib().eeseg_set_option(13, 1280)
+    for m16, (y, sums) in outs.items():
+        close(nchw(y), want, tol(torch.bfloat16), f"mfma16={m16} vs torch")
+        if sums is not None:
+            flat = raw.permute(1, 0, 2, 3).reshape(Cout, -1).double()
+            close(sums[0].cpu(), flat.sum(1).float(), 2e-3, f"mfma16={m16} sum")
+            close(sums[1].cpu(), (flat * flat).sum(1).float(), 2e-3, f"mfma16={m16} sum of squares")
+    close(outs[1][0], outs[0][0], 8e-3, "16x16x32 vs 32x32x16")
