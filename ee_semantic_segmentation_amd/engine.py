@@ -45,9 +45,11 @@ class Config:
         self._side = None                    # the two kernels fill each other's partially filled last block round
         self._side_busy = False
         self._side_keep = []                 # tensors the side stream still reads (freed after the join)
-        # SyncBN backward: the weight gradient of layer L is held back and issued right after layer L-1's statistics
-        # all-reduce has been launched, so it runs while that (latency-bound) collective is in flight
-        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "1") != "0"
+        # SyncBN backward, opt-in (EESEG_DEFER_WGRAD=1): the weight gradient of layer L is held back and issued right after
+        # layer L-1's statistics all-reduce has been launched ASYNCHRONOUSLY, so it runs while that (latency-bound) collective
+        # is in flight.  Off by default: unmeasurable with one rank, and one run of the 1-rank rehearsal died in RCCL's watchdog
+        # (hipErrorCapturedEvent on an event query) with the asynchronous form - the default keeps the synchronous call
+        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "0") == "1"
         self._deferred = None
 
     def world(self):
@@ -410,9 +412,12 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
         sums = sums.clone() if pair is not None else sums
-        work = cfg.all_reduce_begin(sums)
-        cfg.run_deferred()                   # the layer above's weight gradient fills the collective's latency
-        cfg.all_reduce_end(work)
+        if cfg.defer_wgrad:
+            work = cfg.all_reduce_begin(sums)
+            cfg.run_deferred()               # the layer above's weight gradient fills the collective's latency
+            cfg.all_reduce_end(work)
+        else:
+            _allreduce(cfg, sums)
     dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
                               scale_shift=ss, dx=dc_out)        # dc_out: the caller's buffer for the conv-output gradient
     gv = cfg.gview(conv.weight)
