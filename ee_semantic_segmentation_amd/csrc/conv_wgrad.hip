@@ -261,7 +261,49 @@ constexpr int WB_LDS = 8 * WHT;
 #define WB_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 // FAST: 64 consecutive pixels span at most two image rows (Wout > 64): the in-loop iterator is straight-line code.
-template <bool FAST>
+// accumulators of one wave as [cout half i][cin block j][group g][4 floats] for the two MFMA shapes (conv_igemm.hip BigAcc)
+template <bool M16> struct WgAcc;
+template <> struct WgAcc<false> {
+    f32x16 a[2][4];
+    __device__ __forceinline__ float get(int i, int j, int g, int e) const { return a[i][j][4 * g + e]; }
+    __device__ __forceinline__ f32x4 get4(int i, int j, int g) const {
+        return f32x4{a[i][j][4 * g], a[i][j][4 * g + 1], a[i][j][4 * g + 2], a[i][j][4 * g + 3]};
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[i][j][e] = 0.f;
+    }
+};
+template <> struct WgAcc<true> {
+    f32x4 a[2][4][4];
+    __device__ __forceinline__ float get(int i, int j, int g, int e) const { return a[i][j][g][e]; }
+    __device__ __forceinline__ f32x4 get4(int i, int j, int g) const { return a[i][j][g]; }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a[i][j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+};
+// group g, lane -> (first of the 4 cout rows, cin column) inside a 32 x 32 sub-block
+template <bool M16> __device__ __forceinline__ int wg_sub_co(int g, int lane) {
+    return M16 ? (g >> 1) * 16 + (lane >> 4) * 4 : 8 * g + 4 * (lane >> 5);
+}
+template <bool M16> __device__ __forceinline__ int wg_sub_ci(int g, int lane) {
+    return M16 ? (g & 1) * 16 + (lane & 15) : (lane & 31);
+}
+
+// M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (see conv_big_kernel: same cycles per FLOP, higher clock).  A transposing
+// read block is 4 pixel rows x 16 channels per 16-lane group either way; the 16x16 operand wants pixels 8g .. 8g+7 of a 32-pixel
+// K step in group g = lane >> 4 (all four groups the same 16 channels), so lanes 0-31 touch rows {tq, 8 + tq} x 32 bytes: the
+// source-chunk swizzle gains a 32-byte XOR on row bit 3 to keep those on different banks.
+template <bool FAST, bool M16>
 __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef __attribute__((address_space(3))) s16x4* lds_tr;
@@ -283,7 +325,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
 
     // DMA role: one wave-instruction = 4 pixel rows x 256 B; per half tile a thread fetches rows drow, drow+32
     const int drow = wave * 4 + (lane >> 4);
-    const int lc = ((lane & 15) ^ ((drow & 3) << 2)) * 8;        // local channel of the SOURCE chunk (swizzle)
+    const int lc = ((lane & 15) ^ ((drow & 3) << 2) ^ (M16 ? ((drow >> 3) & 1) << 1 : 0)) * 8;   // local channel of the SOURCE chunk (swizzle)
     int coW[2], ciX[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -473,14 +515,34 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     };
 
     const int wc = wave & 3, wp = wave >> 2;
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = M16 ? (lane & 15) : (lane & 31), fh = M16 ? (lane >> 4) : (lane >> 5);
     const int tq = (lane >> 2) & 3;                               // row of the 4x16 transposing-read block
-    const int chl = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // first of my 4 channels inside a 32-wide fragment
+    const int chl = M16 ? 4 * (lane & 3) : 16 * ((lane >> 4) & 1) + 4 * (lane & 3);   // first of my 4 channels inside a 32-wide fragment
     const int trow = (8 * fh + tq) * 256;
     // The transposing reads are inline asm: behind the builtin, hipcc (ROCm 7.2) waits vmcnt(0) before every LDS read
     // that follows an LDS-DMA issue, which would drain the load pipeline twice per K tile.  The matching
     // s_waitcnt lgkmcnt(0) (lgk_wait*) names the fragments as in/out operands so no MFMA can be scheduled above it.
     auto rd = [&](const char* base, int lch, bf16x8 (&f)[4]) {
+        if constexpr (M16) {
+            // f[rb * 2 + k2]: channels lch + 16rb .. +15, pixels 32k2 + 8g .. + 7 (two reads of 4 rows)
+            const uint32_t a0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(
+                base + trow + ((lch * 2) ^ (tq << 6) ^ ((fh & 1) << 5))));
+            const uint32_t a1 = a0 ^ 32u;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                union { i32x2 h[2]; bf16x8 v; } u;
+                const uint32_t a = (ks >> 1) ? a1 : a0;
+                if ((ks & 1) == 0) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[0]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(u.h[1]) : "v"(a) : "memory");
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(u.h[0]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(u.h[1]) : "v"(a) : "memory");
+                }
+                f[ks] = u.v;
+            }
+            return;
+        }
         const uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)(base + trow + ((lch * 2) ^ (tq << 6))));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -512,23 +574,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]),
                      "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : : "memory");
     };
-    auto mma4 = [&](const bf16x8 (&a)[4], const bf16x8 (&b0)[4], const bf16x8 (&b1)[4], f32x16& c0, f32x16& c1) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b0[ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b1[ks], c1, 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    WgAcc<M16> A;
+    A.zero();
+    auto& acc = A.a;
+// MFMA number n (0..15) of a 16x16x32 phase (conv_big_kernel's EESEG_M16)
+#define EESEG_W16(W_, X0_, X1_, I_, J0_, n_) { \
+        constexpr int k2_ = (n_) >> 3, rb_ = ((n_) >> 2) & 1, xs_ = ((n_) >> 1) & 1, cb_ = (n_) & 1; \
+        acc[I_][(J0_) + xs_][rb_ * 2 + cb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
+            W_[rb_ * 2 + k2_], (xs_ ? X1_ : X0_)[cb_ * 2 + k2_], acc[I_][(J0_) + xs_][rb_ * 2 + cb_], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0); }
 
     // schedule and wait counts: see conv_big_kernel (phase 1: XB(t+1) | phase 3: XA(t+2), W0(t+2) | phase 4: W1(t+2))
     // The read slots hold only the transposing LDS reads and the counted wait; DMA issues are pinned between the MFMAs
@@ -562,18 +616,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         WB_BARRIER();
         lgk_wait12(w0, xa0, xa1);
         bool l2;
+        auto mma_phase1 = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (M16) {
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    const int k2 = n >> 3, rb = (n >> 2) & 1, xs = (n >> 1) & 1, cb = n & 1;
+                    acc[0][xs][rb * 2 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        w0[rb * 2 + k2], (xs ? xa1 : xa0)[cb * 2 + k2], acc[0][xs][rb * 2 + cb], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xa0[ks], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[ks], xa1[ks], acc[0][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
         if constexpr (FAST) {
             l2 = advance_fast();               // -> K tile t+2, straight-line code between the MFMAs
-            mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+            mma_phase1();
 #pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) {
+            for (int g8 = 0; g8 < (M16 ? 16 : 8); ++g8) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-                __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, M16 ? 5 : 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, M16 ? 3 : 6, 0);
             }
             if (need_skip) l2 = advance_skip();
         } else {
-            mma4(w0, xa0, xa1, acc[0][0], acc[0][1]);
+            mma_phase1();
             l2 = next_tile();
         }
         WB_BARRIER();
@@ -582,38 +654,64 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
         WB_BARRIER();
         lgk_wait4(w1);
         __builtin_amdgcn_s_setprio(1);
-        EESEG_WM(w1[0], xa0[0], acc[1][0]) dmaX1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[0], xa1[0], acc[1][1]) dmaX1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[1], xa0[1], acc[1][0]) dmaW1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[1], xa1[1], acc[1][1]) dmaW1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[2], xa0[2], acc[1][0]) EESEG_WM(w1[2], xa1[2], acc[1][1])
-        EESEG_WM(w1[3], xa0[3], acc[1][0]) EESEG_WM(w1[3], xa1[3], acc[1][1])
+        if constexpr (M16) {
+            EESEG_W16(w1, xa0, xa1, 1, 0, 0) EESEG_W16(w1, xa0, xa1, 1, 0, 1) dmaX1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xa0, xa1, 1, 0, 2) EESEG_W16(w1, xa0, xa1, 1, 0, 3) dmaX1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xa0, xa1, 1, 0, 4) EESEG_W16(w1, xa0, xa1, 1, 0, 5) dmaW1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xa0, xa1, 1, 0, 6) EESEG_W16(w1, xa0, xa1, 1, 0, 7) dmaW1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xa0, xa1, 1, 0, 8) EESEG_W16(w1, xa0, xa1, 1, 0, 9) EESEG_W16(w1, xa0, xa1, 1, 0, 10) EESEG_W16(w1, xa0, xa1, 1, 0, 11)
+            EESEG_W16(w1, xa0, xa1, 1, 0, 12) EESEG_W16(w1, xa0, xa1, 1, 0, 13) EESEG_W16(w1, xa0, xa1, 1, 0, 14) EESEG_W16(w1, xa0, xa1, 1, 0, 15)
+        } else {
+            EESEG_WM(w1[0], xa0[0], acc[1][0]) dmaX1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[0], xa1[0], acc[1][1]) dmaX1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[1], xa0[1], acc[1][0]) dmaW1(s, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[1], xa1[1], acc[1][1]) dmaW1(s, 0, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[2], xa0[2], acc[1][0]) EESEG_WM(w1[2], xa1[2], acc[1][1])
+            EESEG_WM(w1[3], xa0[3], acc[1][0]) EESEG_WM(w1[3], xa1[3], acc[1][1])
+        }
         __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
         rd(sb + WHT, wp * 64 + chl, xb0); rd(sb + WHT, wp * 64 + 32 + chl, xb1);
         WB_BARRIER();
         lgk_wait8(xb0, xb1);
         __builtin_amdgcn_s_setprio(1);
-        EESEG_WM(w1[0], xb0[0], acc[1][2]) dmaW1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[0], xb1[0], acc[1][3]) dmaW1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w1[1], xb0[1], acc[1][2]) EESEG_WM(w1[1], xb1[1], acc[1][3])
-        EESEG_WM(w1[2], xb0[2], acc[1][2]) EESEG_WM(w1[2], xb1[2], acc[1][3])
-        EESEG_WM(w1[3], xb0[3], acc[1][2]) EESEG_WM(w1[3], xb1[3], acc[1][3])
+        if constexpr (M16) {
+            EESEG_W16(w1, xb0, xb1, 1, 2, 0) EESEG_W16(w1, xb0, xb1, 1, 2, 1) dmaW1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xb0, xb1, 1, 2, 2) EESEG_W16(w1, xb0, xb1, 1, 2, 3) dmaW1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w1, xb0, xb1, 1, 2, 4) EESEG_W16(w1, xb0, xb1, 1, 2, 5) EESEG_W16(w1, xb0, xb1, 1, 2, 6) EESEG_W16(w1, xb0, xb1, 1, 2, 7)
+            EESEG_W16(w1, xb0, xb1, 1, 2, 8) EESEG_W16(w1, xb0, xb1, 1, 2, 9) EESEG_W16(w1, xb0, xb1, 1, 2, 10) EESEG_W16(w1, xb0, xb1, 1, 2, 11)
+            EESEG_W16(w1, xb0, xb1, 1, 2, 12) EESEG_W16(w1, xb0, xb1, 1, 2, 13) EESEG_W16(w1, xb0, xb1, 1, 2, 14) EESEG_W16(w1, xb0, xb1, 1, 2, 15)
+        } else {
+            EESEG_WM(w1[0], xb0[0], acc[1][2]) dmaW1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[0], xb1[0], acc[1][3]) dmaW1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w1[1], xb0[1], acc[1][2]) EESEG_WM(w1[1], xb1[1], acc[1][3])
+            EESEG_WM(w1[2], xb0[2], acc[1][2]) EESEG_WM(w1[2], xb1[2], acc[1][3])
+            EESEG_WM(w1[3], xb0[3], acc[1][2]) EESEG_WM(w1[3], xb1[3], acc[1][3])
+        }
         __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
         WB_WAIT(10);
         WB_BARRIER();
         __builtin_amdgcn_s_setprio(1);
-        EESEG_WM(w0[0], xb0[0], acc[0][2]) dmaX1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w0[0], xb1[0], acc[0][3]) dmaX1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
-        EESEG_WM(w0[1], xb0[1], acc[0][2]) EESEG_WM(w0[1], xb1[1], acc[0][3])
-        EESEG_WM(w0[2], xb0[2], acc[0][2]) EESEG_WM(w0[2], xb1[2], acc[0][3])
-        EESEG_WM(w0[3], xb0[3], acc[0][2]) EESEG_WM(w0[3], xb1[3], acc[0][3])
+        if constexpr (M16) {
+            EESEG_W16(w0, xb0, xb1, 0, 2, 0) EESEG_W16(w0, xb0, xb1, 0, 2, 1) dmaX1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w0, xb0, xb1, 0, 2, 2) EESEG_W16(w0, xb0, xb1, 0, 2, 3) dmaX1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_W16(w0, xb0, xb1, 0, 2, 4) EESEG_W16(w0, xb0, xb1, 0, 2, 5) EESEG_W16(w0, xb0, xb1, 0, 2, 6) EESEG_W16(w0, xb0, xb1, 0, 2, 7)
+            EESEG_W16(w0, xb0, xb1, 0, 2, 8) EESEG_W16(w0, xb0, xb1, 0, 2, 9) EESEG_W16(w0, xb0, xb1, 0, 2, 10) EESEG_W16(w0, xb0, xb1, 0, 2, 11)
+            EESEG_W16(w0, xb0, xb1, 0, 2, 12) EESEG_W16(w0, xb0, xb1, 0, 2, 13) EESEG_W16(w0, xb0, xb1, 0, 2, 14) EESEG_W16(w0, xb0, xb1, 0, 2, 15)
+        } else {
+            EESEG_WM(w0[0], xb0[0], acc[0][2]) dmaX1(s, 1, 0); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w0[0], xb1[0], acc[0][3]) dmaX1(s, 1, 1); __builtin_amdgcn_sched_barrier(0);
+            EESEG_WM(w0[1], xb0[1], acc[0][2]) EESEG_WM(w0[1], xb1[1], acc[0][3])
+            EESEG_WM(w0[2], xb0[2], acc[0][2]) EESEG_WM(w0[2], xb1[2], acc[0][3])
+            EESEG_WM(w0[3], xb0[3], acc[0][2]) EESEG_WM(w0[3], xb1[3], acc[0][3])
+        }
         __builtin_amdgcn_s_setprio(0);
         WB_BARRIER();
         l0 = l1; l1 = l2; s ^= 1;
     }
 #undef EESEG_WM
+#undef EESEG_W16
     if (!lagging) WB_BARRIER();
     WB_WAIT(0);
     if (p.slabs) {
@@ -627,8 +725,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(ws + ((i * 4 + j) * 4 + g) * 256) =
-                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(ws + ((i * 4 + j) * 4 + g) * 256) = A.get4(i, j, g);
         return;
     }
     if (!any) return;
@@ -640,12 +737,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ci = ci0 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + fr;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + i * 128 + wc * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int g = e >> 2;
+                const int ci = ci0 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + wg_sub_ci<M16>(g, lane);
+                const int co = co0 + i * 128 + wc * 32 + wg_sub_co<M16>(g, lane) + (e & 3);
                 float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
-                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)dst, acc[i][j][e]);
+                __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)dst, A.get(i, j, g, e & 3));
             }
         }
     }
@@ -656,6 +754,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
 // G > 1 (few output tiles, many splits: tiles x 8 blocks alone would read the slabs at a fraction of the memory rate):
 // group g sums splits [g*n/G, (g+1)*n/G) into a second-level slab; a second launch with G = 1 folds those into dW.
 // Fixed summation order at both levels: bitwise reproducible.
+template <bool M16>
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p, const float* __restrict__ src, int nsplit,
                                                                 float* dst_slabs) {
     const int taps = p.R * p.S;
@@ -688,15 +787,16 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p, const flo
             for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(wd + ((i * 4 + j) * 4 + q) * 256) = a[q];
             continue;
         }
-        const int ci = ci_t * 256 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + fr;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+            const int ci = ci_t * 256 + (j >> 1) * 128 + wp * 64 + (j & 1) * 32 + wg_sub_ci<M16>(q, lane);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int co = co_t * 256 + i * 128 + wc * 32 + k + 8 * q + 4 * fh;
+                const int co = co_t * 256 + i * 128 + wc * 32 + wg_sub_co<M16>(q, lane) + k;
                 float* dst = p.dw + ((size_t)co * taps + tap) * p.Cin + ci;
                 *dst += a[q][k];
             }
+        }
     }
 }
 
@@ -704,6 +804,7 @@ int g_wgrad_big = 1;                // eeseg_set_wgrad_big(0|1)
 int g_wgrad_big_min_ktiles = 20;
 int g_wgrad_big_blocks = 256;       // EESEG_OPT_WGRAD_BIG_BLOCKS: concurrent blocks the 256x256 wgrad kernel sizes its K split for
 int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this many rounds of them
+int g_wgrad_m16 = 0;                // eeseg_set_wgrad_big(on | 16): 256x256 kernel on v_mfma_f32_16x16x32_bf16
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
 int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_target_blocks); 0 = by the cost model below
 
@@ -746,6 +847,7 @@ extern "C" int64_t eeseg_wgrad_workspace(void) {
 
 extern "C" int eeseg_set_wgrad_big(int on) {
     g_wgrad_slabs = (on & 4) ? 1 : 0;
+    g_wgrad_m16 = (on & 16) ? 1 : 0;
     on &= 3;
     g_wgrad_big = on > 2 ? 2 : on;
     return EESEG_OK;
@@ -831,19 +933,25 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
                           ? reinterpret_cast<float*>(a->workspace) : nullptr;
             g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_BIG;
-            if (p.q64 == 0)
-                hipLaunchKernelGGL(conv_wgrad_big_kernel<true>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
-            else
-                hipLaunchKernelGGL(conv_wgrad_big_kernel<false>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, p);
+            const bool m16 = g_wgrad_m16 != 0;
+            const dim3 grid((unsigned)(tiles * splits));
+            if (p.q64 == 0) {
+                if (m16) hipLaunchKernelGGL((conv_wgrad_big_kernel<true, true>), grid, dim3(512), 0, st, p);
+                else hipLaunchKernelGGL((conv_wgrad_big_kernel<true, false>), grid, dim3(512), 0, st, p);
+            } else {
+                if (m16) hipLaunchKernelGGL((conv_wgrad_big_kernel<false, true>), grid, dim3(512), 0, st, p);
+                else hipLaunchKernelGGL((conv_wgrad_big_kernel<false, false>), grid, dim3(512), 0, st, p);
+            }
+            auto reduce = [&](dim3 g, const float* src, int n, float* dst) {
+                if (m16) hipLaunchKernelGGL(wgrad_slab_reduce_kernel<true>, g, dim3(256), 0, st, p, src, n, dst);
+                else hipLaunchKernelGGL(wgrad_slab_reduce_kernel<false>, g, dim3(256), 0, st, p, src, n, dst);
+            };
             if (p.slabs && G > 1) {
                 float* lvl2 = p.slabs + (size_t)tiles * splits * 65536;
-                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), (unsigned)G), dim3(256), 0, st, p,
-                                   (const float*)p.slabs, (int)splits, lvl2);
-                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), 1), dim3(256), 0, st, p,
-                                   (const float*)lvl2, (int)G, (float*)nullptr);
+                reduce(dim3((unsigned)(tiles * 8), (unsigned)G), (const float*)p.slabs, (int)splits, lvl2);
+                reduce(dim3((unsigned)(tiles * 8), 1), (const float*)lvl2, (int)G, (float*)nullptr);
             } else if (p.slabs) {
-                hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)(tiles * 8), 1), dim3(256), 0, st, p,
-                                   (const float*)p.slabs, (int)splits, (float*)nullptr);
+                reduce(dim3((unsigned)(tiles * 8), 1), (const float*)p.slabs, (int)splits, (float*)nullptr);
             }
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;

@@ -72,7 +72,8 @@ int eeseg_set_ew_grid_cap(int blocks);
 int eeseg_set_wgrad_target_blocks(int blocks);
 /* bf16 weight gradients with Cout % 256 == 0 and Cin % 256 == 0: 1 (default) = 256x256-tile kernel when every block
  * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel); +4 = combine the K splits through
- * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics */
+ * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics; +16 = the 256x256-tile kernel computes with
+ * v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same results up to fp32 summation order; measured neutral, default off) */
 int eeseg_set_wgrad_big(int on);
 /* K-split sizing of the 256x256 weight-gradient kernel: aim at `blocks` concurrent blocks (default 256 = one per CU) and
  * at most `rounds` rounds of them (default 8).  Fewer blocks = fewer fp32 partial tiles to combine; use with the weight

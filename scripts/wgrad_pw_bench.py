@@ -34,6 +34,7 @@ for H, Cin, Cout, k in ((65, 1024, 256, 1), (65, 256, 1024, 1), (65, 512, 2048, 
     lib().eeseg_set_wgrad_big(0); row["128-tile"] = timeit(fn)
     lib().eeseg_set_wgrad_big(1); row["model"] = timeit(fn)
     lib().eeseg_set_wgrad_big(2); row["256 atomics"] = timeit(fn)
+    lib().eeseg_set_wgrad_big(2 | 16); row["256 atomics 16x16x32"] = timeit(fn)
     K.WGRAD_SLABS = True
     lib().eeseg_set_wgrad_big(2 | 4); row["256 slabs"] = timeit(fn)
     K.WGRAD_SLABS = False

@@ -674,19 +674,21 @@ def test_wgrad_256_tile_kernel_matches_the_128_tile_kernel(shape):
     dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(DEV).bfloat16()
     outs = {}
     try:
-        for big in (0, 2, 6):                   # 2 = force the 256x256 kernel (K splits by atomics), 6 = same through slabs
+        # 2 = force the 256x256 kernel (K splits by atomics), 6 = same through slabs; +16 = on v_mfma_f32_16x16x32_bf16
+        # (other transposing-read geometry, LDS swizzle, accumulator layout in the atomics / slabs / slab reduce)
+        for big in (0, 2, 6, 18, 22):
             lib().eeseg_set_wgrad_big(big)
-            K.WGRAD_SLABS = big == 6
+            K.WGRAD_SLABS = bool(big & 4)
             dw = K.conv_wgrad(x, dy, k, k, s, p, d)
             dw2 = K.conv_wgrad(x, dy, k, k, s, p, d, out=dw.clone(), accumulate=True)
-            if big == 6:                        # slab combine sums the K splits in a fixed order: bitwise reproducible
+            if big & 4:                         # slab combine sums the K splits in a fixed order: bitwise reproducible
                 assert torch.equal(K.conv_wgrad(x, dy, k, k, s, p, d), dw)
             torch.cuda.synchronize()
             outs[big] = (dw, dw2)
     finally:
         lib().eeseg_set_wgrad_big(1)
         K.WGRAD_SLABS = False
-    for mode in (2, 6):
+    for mode in (2, 6, 18, 22):
         close(outs[mode][0], outs[0][0], 2e-5, f"dw (mode {mode})")
         close(outs[mode][1], 2 * outs[0][0], 2e-5, f"dw accumulate (mode {mode})")
     # and against fp32 torch on the same bf16 inputs
