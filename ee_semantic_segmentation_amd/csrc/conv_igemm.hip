@@ -784,7 +784,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                             : *reinterpret_cast<const Frag*>(a + (((ks * 2 + fh) ^ fsw) << 4));
         };
 // MFMA number n (0..15) of a 16x16x32 phase: K step k2 = n>>3 outermost, so the 8 accumulators of the phase are each
-// touched once per K step (no back-to-back MFMAs on one accumulator)
+// touched once per K step (no back-to-back MFMAs on one accumulator).  The LDS-DMA issues of a phase sit behind MFMA pairs
+// (after n = 1, 3, 5, 7); one issue per MFMA (n = 0..3) measured 1-3 % slower, one per three or four MFMAs the same.
 #define EESEG_M16(W_, X0_, X1_, I_, J0_, n_) { \
             constexpr int k2_ = (n_) >> 3, rb_ = ((n_) >> 2) & 1, xs_ = ((n_) >> 1) & 1, cb_ = (n_) & 1; \
             acc[I_][(J0_) + xs_][rb_ * 2 + cb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
