@@ -40,16 +40,25 @@ out = ["# Round 2 - MFMA / LDS utilisation of the conv kernels at the metric's s
        "`rocprofv3 --pmc ... --kernel-trace` passes over `scripts/conv_one.py` (counters in their own runs, no other trace domain).  Values are per\n"
        "dispatch, summed over the chip (32 shader engines for `SQ_BUSY_CYCLES`, 1024 SIMDs for `SQ_VALU_MFMA_BUSY_CYCLES`, 256 CUs for\n"
        "`SQ_LDS_IDX_ACTIVE`).  MFMA pipe utilisation = MFMA_BUSY / (1024 SIMDs x kernel cycles), kernel cycles = SQ_BUSY_CYCLES / 32;\n"
-       "`SQ_VALU_MFMA_BUSY_CYCLES` = 32 x `SQ_INSTS_MFMA` (one `v_mfma_f32_32x32x16_bf16` holds a SIMD's matrix pipe for 32 cycles).\n",
+       "`SQ_VALU_MFMA_BUSY_CYCLES` = 32 x `SQ_INSTS_MFMA` for `v_mfma_f32_32x32x16_bf16` (the weight-gradient kernel), 16 x for\n"
+       "`v_mfma_f32_16x16x32_bf16` (`conv_big_kernel` since the 16x16 port: twice the instructions, the same busy cycles).\n",
        "| layer (H W Cin Cout k s p d B pass) | kernel | SQ_BUSY_CYCLES | kernel cycles | SQ_INSTS_MFMA | MFMA_BUSY | **MFMA pipe utilisation** | LDS array busy | LDS bank conflicts | waves parked (WAIT_ANY / WAVE_CYCLES) |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
 for r in rows:
     out.append(f"| {r[0]} | `{r[1]}` | {r[2]:.3g} | {r[3]:.3g} | {r[4]:.3g} | {r[5]:.3g} | **{100*r[6]:.1f} %** | {100*r[7]:.1f} % | {r[8]:.2g} | {100*r[9]:.0f} % |")
 u = [round(r[6] * 100, 1) for r in rows]
 out.append(f"""
 Reading.  The 3x3 stack the north-star target names holds the matrix pipes {u[2]:.0f}-{u[0]:.0f} % of the cycles (atrous 2048->256 {u[0]} %, 512->512 {u[1]} %,
-256->256 {u[2]} %; weight gradient of the atrous layer {u[5]} %).  The chip runs these bf16 MFMA loops at ~1.8-1.9 GHz (kernel cycles / wall time;
-nominal 2.4 GHz: MI355X_MICROARCH.md 'DVFS give-back'), so 70 % of the pipe cycles is ~53 % of the NOMINAL 2.5 PFLOP/s - `roofline.frac`
-and `roofline.stack_3x3.frac` in the bench line are priced against the nominal peak, this table against the clock the chip actually holds.
+256->256 {u[2]} %; weight gradient of the atrous layer {u[5]} %).  The chip lowers its clock under these bf16 MFMA loops (kernel cycles / wall
+time; nominal 2.4 GHz: MI355X_MICROARCH.md 'DVFS give-back'), so `roofline.frac` and `roofline.stack_3x3.frac` in the bench line are priced
+against the nominal peak, this table against the cycles the chip actually ran.
+
+**32x32x16 -> 16x16x32 (`EESEG_OPT_CONV_MFMA16`), same three forward layers, same counters, previous evidence run of this round vs this one:**
+kernel cycles 1.62e6 -> {rows[0][3]:.3g} (atrous 2048->256), 9.38e5 -> {rows[1][3]:.3g} (512->512), 2.88e5 -> {rows[2][3]:.3g} (256->256); pipe utilisation
+68.5 / 64.8 / 52.9 % -> {u[0]} / {u[1]} / {u[2]} %; wall time per call (`scripts/m16_bench.py`, same box) 985 -> 924, 541 -> 512, 167.8 -> 161.8 us.
+The 16x16 form needs ~9 % MORE cycles (an MFMA burst of the other wave group now takes half of the SIMD's issue slots instead of a quarter, so
+the LDS-read slot beside it stretches: `SQ_WAIT_INST_LDS` 4.2e7 -> 5.2e7) and still finishes 3-7 % EARLIER: the clock the chip holds
+under it is that much higher (1.62e6 cycles / 985 us = 1.65 GHz vs 1.77e6 / 924 us = 1.92 GHz on the atrous layer) - the guide's item 7, and the
+reason cycle counts alone would have rejected the change.
 256->256 loses its 15 points to tile quantisation (32 x 65 x 65 pixels = 528.1 tiles of 256 on 256 CUs: two rounds + a K-split tail + the
 fix-up) and to the 7.5 us per-round fixed cost on a 36-K-tile loop.  The 1x1 layers are HBM-bound (SURVEY 8d): their figure of merit is
 bytes/s, not MFMA cycles - `roofline.by_shape` in the bench line prices every layer against its own max(flops/peak, bytes/BW).  The
