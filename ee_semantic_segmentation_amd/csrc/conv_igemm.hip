@@ -19,6 +19,10 @@
 //   train-mode BatchNorm + coalesced 16-byte row stores (+residual, ReLU).
 #include "eeseg_common.h"
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): behind a tile's output stores (or
+// with the next tile's LDS-DMA in flight) that is a wait for HBM, not for the workgroup.
+#define WS_LDS_BARRIER() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("s_barrier" ::: "memory"); }
+
 namespace {
 
 struct ConvP {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvP p) {
                 }
             }
         }
-        __syncthreads();
+        WS_LDS_BARRIER();            // LDS only: the tile's output stores keep draining
         if (tid < 2 * BN) {
             const int which = tid / BN, col = tid - which * BN;
             // waves that share a chunk column set: with CPR<=64 every wave covers all chunks
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                 sRed[(wave * 2 + 1) * BIGT + lane * 8 + e] = s2[e];
             }
         }
-        __syncthreads();
+        WS_LDS_BARRIER();            // LDS only: the tile's output stores keep draining
         const int which = tid >> 8, col = tid & 255;
         float t = 0.f;
 #pragma unroll
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(256) void conv_big_fixup_kernel(ConvP p) {
                 sRed[(wc * 2 + 1) * BIGT + lane * 8 + e] = s2[e];
             }
         }
-        __syncthreads();
+        WS_LDS_BARRIER();            // LDS only: the tile's output stores keep draining
         const int col = tid;                                  // 256 threads = 256 couts, both sums
         const int srow = 2 * mt + wp;
         if (n0 + col < p.Cout && srow < p.m_tiles) {
@@ -1445,7 +1449,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
                 sRed[(wave * 2 + 1) * PW_BN + lane * 8 + e] = s2[e];
             }
         }
-        __syncthreads();
+        WS_LDS_BARRIER();            // LDS only: the tile's output stores keep draining
         const int col = tid;                                   // 256 threads = 256 couts, both sums; one stat row per 128 pixels
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
@@ -1473,6 +1477,9 @@ constexpr int WS_ROWB = WS_K * 2;                  // 512-byte LDS rows: X [px][
 constexpr int WS_SLOT = WS_HALF * WS_ROWB;         // 32 KiB
 constexpr int WS_LDS = 2 * WS_SLOT + 4 * 2 * 256 * 4 + 16;
 
+// RES: the call adds a residual (a data-gradient: no BN partial sums) - the residual registers and the statistics registers
+// never live in the same instantiation, which is what keeps the weights from spilling
+template <bool RES>
 __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
     typedef bf16_t T;
     typedef Mma<T>::Frag Frag;
@@ -1526,11 +1533,13 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
         }
     }
     WS_STAMP(1);
-    const T* res = reinterpret_cast<const T*>(p.residual);
+    const T* res = RES ? reinterpret_cast<const T*>(p.residual) : nullptr;
+    float* const stats = RES ? nullptr : p.stats;
     T* yout = reinterpret_cast<T*>(p.y);
     float* sRed = reinterpret_cast<float*>(smem + 2 * WS_SLOT);   // [4 waves][2][256]
     const int c_ = tid & 31, r0_ = tid >> 5;                      // epilogue role: 16-byte chunk c of rows r0 + 8*it
 
+    float stat_half0[2] = {0.f, 0.f};
     for (; mt < n_m; mt += nseq) {
         const int nxt = mt + nseq;
 #pragma unroll 1
@@ -1584,7 +1593,9 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
                     }
             }
             WS_STAMP(4 + half * 6);
-            __syncthreads();                                      // every wave has read its fragments: the slot becomes the staging area
+            // LDS-only barriers from here on (s_waitcnt lgkmcnt(0) + s_barrier): a __syncthreads() also waits vmcnt(0), i.e. for the
+            // next half tile's LDS-DMA and the output stores in flight - ~2 us of HBM latency per barrier, five times per half tile
+            WS_LDS_BARRIER();                                     // every wave has read its fragments: the slot becomes the staging area
             // ---- stage [px][cout] (16-byte chunks XOR-ed with px & 15: the 512-byte pitch maps every row to the same banks) ----
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1595,7 +1606,7 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x4*>(d + j * 32 * WS_ROWB) = packed[j][i][gq];
                 }
-            __syncthreads();
+            WS_LDS_BARRIER();
             WS_STAMP(5 + half * 6);
             // ---- two passes of 4 rows x 16 B per thread: read back, residual (+ mask), ReLU, store, BN partial sums.  The next
             //      half tile's DMA is issued after the second read-back (the slot is free then) and after the residual loads
@@ -1604,28 +1615,33 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
             f32x2 a1[4], a2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+            // the residual rows of BOTH passes are requested first: two dependent HBM round trips (one per pass) were half of this
+            // phase; the registers are free here (accumulators, B fragments and the packed tiles are dead)
+            i32x4 rr[2][4];
+            unsigned mb[2][4];
+            if (RES) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int m = mh + r0 + 8 * (ps * 4 + it);
+                        rr[ps][it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
+                        mb[ps][it] = (p.resmask && m < p.M) ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0xffu;
+                    }
+            }
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
-                i32x4 rq[4], rr[4];
-                unsigned mb[4];
+                i32x4 rq[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = r0 + 8 * (ps * 4 + it);
                     rq[it] = *reinterpret_cast<const i32x4*>(slot + row * WS_ROWB + ((c ^ (row & 15)) << 4));
                 }
-                if (res != nullptr) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int m = mh + r0 + 8 * (ps * 4 + it);
-                        rr[it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
-                        mb[it] = (p.resmask && m < p.M) ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0xffu;
-                    }
-                }
                 if (ps == 1) {
-                    __syncthreads();                              // staging consumed by every thread: the slot is free
+                    WS_LDS_BARRIER();                             // staging consumed by every thread: the slot is free
                     issue(nxt, half, nxt < n_m);                  // next tile's half into it (out-of-range loads past the end)
                 }
-                if (res != nullptr || p.relu) {
+                if (RES || p.relu) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         union { i32x4 q; T e[8]; } u, ur;
@@ -1633,8 +1649,8 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
                         float f[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = to_f32(u.e[e]);
-                        if (res != nullptr) {
-                            ur.q = p.resmask ? mask_chunk_bf16(rr[it], mb[it]) : rr[it];
+                        if (RES) {
+                            ur.q = p.resmask ? mask_chunk_bf16(rr[ps][it], mb[ps][it]) : rr[ps][it];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(ur.e[e])));
                         }
@@ -1652,7 +1668,7 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
                     const int m = mh + r0 + 8 * (ps * 4 + it);
                     if (m < p.M) *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = rq[it];
                 }
-                if (p.stats) {
+                if (!RES && stats) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         if (mh + r0 + 8 * (ps * 4 + it) < p.M) {
@@ -1668,8 +1684,8 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
                 }
             }
             WS_STAMP(6 + half * 6);
-            if (p.stats) {                                        // one stat row per 128-pixel tile: the first half writes it,
-                                                                  // the second adds (same thread, in program order)
+            if (!RES && stats) {                                  // one stat row per 128-pixel tile: the first half keeps its sums,
+                                                                  // the second adds its own and stores (same thread)
                 float s1[8], s2[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1688,16 +1704,16 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
                         sRed[(wave * 2 + 1) * 256 + lane * 8 + e] = s2[e];
                     }
                 }
-                __syncthreads();
+                WS_LDS_BARRIER();
                 const int col = tid;
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
                     const float t = sRed[(0 * 2 + which) * 256 + col] + sRed[(1 * 2 + which) * 256 + col] +
                                     sRed[(2 * 2 + which) * 256 + col] + sRed[(3 * 2 + which) * 256 + col];
-                    float* dst = p.stats + ((size_t)mt * 2 + which) * p.Cout + n0 + col;
-                    *dst = half == 0 ? t : *dst + t;
+                    if (half == 0) stat_half0[which] = t;         // kept in a register: one store per tile, no read-modify-write
+                    else stats[((size_t)mt * 2 + which) * p.Cout + n0 + col] = stat_half0[which] + t;
                 }
-                __syncthreads();                                  // sRed is rewritten by the next half
+                WS_LDS_BARRIER();                                 // sRed is rewritten by the next half
             }
             WS_STAMP(7 + half * 6);
         }
@@ -1989,6 +2005,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
         // 256->1024 150 -> 133 us, with a residual 230 -> 145 us, 512->2048 410 -> 370 us; contracting layers such as
         // 1024->256 stay on the 256-tile kernel: 101 vs 106 us, their K loop dominates and the bigger tile re-reads W less)
         if (p.pointwise && g_conv_pws && a->Cin == WS_K && !a->n_active && !a->scale && !a->shift && a->ldy % 8 == 0 &&
+            !(a->residual && a->stats) &&
             (a->Cout >= 2 * a->Cin || a->residual) && M >= 512 * 128) {
             // weight-stationary persistent form (only where a block walks >= 4 pixel tiles: loading its 128 KiB of weights into
             // registers costs 6.6 us): grid = whole groups of 8 blocks per cout tile, two blocks per CU
@@ -2000,7 +2017,8 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
-            hipLaunchKernelGGL(conv_pws_kernel, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
+            if (a->residual) hipLaunchKernelGGL(conv_pws_kernel<true>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL(conv_pws_kernel<false>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
             g_last_conv_kernel = EESEG_KERNEL_CONV_PWS;
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
