@@ -9,7 +9,9 @@ int g_bn_reverse = 0;               // EESEG_OPT_BN_REVERSE: bit 0 bn_apply, bit
 
 int g_colreduce_blocks = 512;        // EESEG_OPT_COLREDUCE_BLOCKS: blocks a column reduction aims at in all (0 = up to 1024 row blocks per
                                      // column block: 8192 blocks and 16 MB of partial sums for a 2048-channel tensor; 512: +0.5..1.4 % end to end)
-int g_bn_rows = 2;                  // EESEG_OPT_BN_ROWS: rows of loads in flight per thread in bn_apply / bn_bwd_apply (1, 2, 4)
+int g_bn_rows = 2;                  // EESEG_OPT_BN_ROWS: rows of loads in flight per thread in bn_apply (1, 2, 4)
+int g_bn_bwd_rows = 1;              // EESEG_OPT_BN_BWD_ROWS: the same for bn_bwd_apply / scale_act_bwd (three streams per row already: one row in
+                                    // flight measured 10-14 % faster than two at 32 x 65 x 65, 3-10 % at 4-16 x 65 x 65; scripts/bn_knob_sweep.py)
 
 namespace {
 
@@ -237,7 +239,10 @@ __device__ __forceinline__ void colreduce_body(F&& elem, long long row_begin, lo
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[k][e] = 0.f;
     if (c0 < C) {
-#pragma unroll 2
+#ifndef EESEG_COLRED_UNROLL
+#define EESEG_COLRED_UNROLL 4     // rows whose loads are in flight per thread; BN backward reduce at 32 x 65 x 65 x 1024: 1: 152 us, 2: 117, 4: 109, 8: 117
+#endif
+#pragma unroll EESEG_COLRED_UNROLL
         for (long long r = row_begin + ty; r < row_end; r += TY) elem(r, c0, acc);
     }
 #pragma unroll
@@ -1273,10 +1278,10 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     const int g = colfixed_grid(rows, C / epc);
     const float inv = (float)(1.0 / count);
     if (dtype == EESEG_BF16) {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+        if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
                            lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+        else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
                            lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
@@ -1284,10 +1289,10 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                            lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
     }
     else {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
                            (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
                            (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
@@ -1310,11 +1315,11 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
     const int epc = 16 / eeseg_dtype_size(dtype);
     const int g = colfixed_grid(rows, C / epc);
     if (dtype == EESEG_BF16) {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+        if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
+        else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);
@@ -1324,11 +1329,11 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
                            (const float*)nullptr, 0);
     }
     else {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
+        else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
                            (const float*)nullptr, 0);

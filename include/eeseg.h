@@ -40,14 +40,15 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_CONV_MFMA16 = 17 /* 256x256 conv kernel: 1 (default) = v_mfma_f32_16x16x32_bf16, 0 = v_mfma_f32_32x32x16_bf16 (same tile, same LDS image, same cycles per FLOP; the chip holds a higher clock on the 16x16 shape: 3-7 % faster) */,
+enum { EESEG_OPT_BN_BWD_ROWS = 18 /* bn_bwd_apply / scale_act_bwd: rows whose loads a thread keeps in flight (1 = default, 2, 4) */,
+       EESEG_OPT_CONV_MFMA16 = 17 /* 256x256 conv kernel: 1 (default) = v_mfma_f32_16x16x32_bf16, 0 = v_mfma_f32_32x32x16_bf16 (same tile, same LDS image, same cycles per FLOP; the chip holds a higher clock on the 16x16 shape: 3-7 % faster) */,
        EESEG_OPT_CONV_COUT_GROUP = 16 /* 256x256 conv kernel, layers with more cout tiles than this: the 32 CUs of an XCD work on `value` cout tiles x 32/value pixel tiles at a time (1, 2, 4, 8; default 0 = all cout tiles of few pixel tiles; an A/B switch, measured neutral on the 8-cout-tile layers) */,
        EESEG_OPT_CONV_PW_ALL = 15 /* 1: every eligible pointwise bf16 layer (Cin <= EESEG_OPT_CONV_PW_MAX_K) on the 128x256 kernel; 0 (default): the rule in eeseg_conv_igemm */,
        EESEG_OPT_CONV_PWS = 14 /* 1 (default): expanding pointwise bf16 layers with Cin = 256 run on the weight-stationary persistent kernel (weights in registers, only activations stream); 0 = the 128x256 kernel */,
        EESEG_OPT_CONV_PW_MAX_K = 13 /* pointwise (1x1, stride 1) bf16 layers with Cout % 256 == 0 and Cin <= value run on the 128x256 two-blocks-per-CU kernel (default 1280; 0 = never) */,
        EESEG_OPT_CONV_SPLIT_MIN_K = 12 /* 256x256 conv kernel: K tiles per K range of a split tail tile, at least (default 4) */,
        EESEG_OPT_COLREDUCE_BLOCKS = 11 /* column reductions (BN backward sums, channel statistics): blocks aimed at in all (default 512); 0 = up to 1024 row blocks per column block */,
-       EESEG_OPT_BN_ROWS = 10 /* bn_apply / bn_bwd_apply: rows whose loads a thread keeps in flight (1, 2 = default, 4) */,
+       EESEG_OPT_BN_ROWS = 10 /* bn_apply: rows whose loads a thread keeps in flight (1, 2 = default, 4) */,
        EESEG_OPT_BN_REVERSE = 9 /* bit 0: bn_apply, bit 1: bn_bwd_apply sweep the rows from the end (the part the producing kernel touched last is still in the caches) */,
        EESEG_OPT_CONV_CUS = 8 /* 256x256 conv kernel: CUs a launch may count on when it sizes its rounds and its K-split tail (default 256; lower it while collectives hold CUs) */,
        EESEG_OPT_CONV_TAIL_MERGE = 7 /* 256x256 kernel: K-split tail blocks and full rounds in ONE launch (default 1) */,
