@@ -576,12 +576,17 @@ template <bool M16> __device__ __forceinline__ int big_sub_px(int g, int lane) {
     return M16 ? (g & 1) * 16 + (lane & 15) : (lane & 31);
 }
 
-template <int MODE, bool M16>
+// SWP (needs M16): software-pipelined K loop - every wave issues the LDS reads of phase p+1 BEFORE the MFMAs of phase p, so a
+// fragment read has a whole MFMA block to land and the eight waves run in lockstep (one barrier per phase) instead of two
+// groups half a phase apart that take turns reading and multiplying.
+template <int MODE, bool M16, bool SWP>
 __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
+    static_assert(M16 || !SWP, "the software-pipelined loop is written for the 16x16x32 shape");
     typedef bf16_t T;
     typedef Mma<T>::Frag Frag;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    __shared__ __attribute__((aligned(16))) char smem[BIG_LDS];
+    // SWP: 8 KiB more for the per-thread tap-visibility masks (4 rows x 512 threads), kept out of the register file in that form
+    __shared__ __attribute__((aligned(16))) char smem[BIG_LDS + (SWP ? 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // MODE 2 (mixed launch): the first p.n_split_blocks blocks are K ranges of the tail tiles (they are dispatched
     // first and finish early), the others are whole tiles 0 .. p.tile_begin-1 - one launch, no idle gap between the two
@@ -695,6 +700,10 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) baseA[k] = ((nb[k] + hb[k] * p.Win + wb[k]) * p.Cin) * 2 + gchunk * 16;
         }
+        if constexpr (SWP) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) reinterpret_cast<unsigned*>(smem + BIG_LDS)[k * 512 + tid] = vmask[k];   // read back by this thread only
+        }
         const int kc_steps = p.Cin / 64;
         const int nk_all = __popc(tapmask) * kc_steps;
         const int k_begin = split_blk ? (int)((long long)split * nk_all / nsplit) : 0;
@@ -752,8 +761,9 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
                 upd = false;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    voffA[k] = (live && ((vmask[k] >> cur_tap) & 1u)) ? (uint32_t)(baseA[k] + dtap) : EESEG_OOB;
-                    voffWl[k] = live ? voffW[k] : EESEG_OOB;
+                    const unsigned vm = SWP ? reinterpret_cast<const unsigned*>(smem + BIG_LDS)[k * 512 + tid] : vmask[k];
+                    voffA[k] = (live && ((vm >> cur_tap) & 1u)) ? (uint32_t)(baseA[k] + dtap) : EESEG_OOB;
+                    if (!SWP) voffWl[k] = live ? voffW[k] : EESEG_OOB;     // SWP selects at the issue (4 registers less)
                 }
             }
             soffA = ci * ROWB;
@@ -809,6 +819,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
         // slot times).  A half tile last read in slot P is refilled in MFMA block P+1: by then the lagging
         // group, half a phase behind, has consumed its slot-P reads too.  Issue order per iteration t (all for K tile t+2,
         // stage s):  MFMA block 2: XA, W0 | block 3: W1 | block 4: XB;  waits (in slot P-1 for the reads of slot P) as before.
+        if constexpr (!SWP) {
         next_tile(); dmaX(0, 0); dmaW(0, 0); dmaW(0, 1); dmaX(0, 1);      // K tile 0
         next_tile(); dmaX(1, 0); dmaW(1, 0); dmaW(1, 1); dmaX(1, 1);      // K tile 1
         BIG_WAIT(8);
@@ -906,8 +917,131 @@ __global__ __launch_bounds__(512) void conv_big_kernel(ConvP p) {
             BIG_BARRIER();
         }
 #undef EESEG_MM
-#undef EESEG_M16
         if (!lagging) BIG_BARRIER();
+        } else {
+        auto dma1s = [&](const __amdgpu_buffer_rsrc_t& rs, int half, int q, uint32_t voff, int soff, int s) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (s * 4 + half) * HT + (q * 64 + w8) * ROWB), 16,
+                                                     (int)voff, soff, 0, 0);
+        };
+        for (int s0 = 0; s0 < 2; ++s0) {                                  // K tiles 0 and 1, in the loop's issue order
+            next_tile();
+            dma1s(rx, 0, 0, voffA[0], soffA, s0); dma1s(rx, 0, 1, voffA[1], soffA, s0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dma1s(rw, 2 + (k >> 1), k & 1, live ? voffW[k] : EESEG_OOB, soffW, s0);
+            dma1s(rx, 1, 0, voffA[2], soffA, s0); dma1s(rx, 1, 1, voffA[3], soffA, s0);
+        }
+#define BIG_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define EESEG_M16x4(W_, X0_, X1_, I_, J0_, n_) EESEG_M16(W_, X0_, X1_, I_, J0_, n_) EESEG_M16(W_, X0_, X1_, I_, J0_, (n_) + 1) \
+        EESEG_M16(W_, X0_, X1_, I_, J0_, (n_) + 2) EESEG_M16(W_, X0_, X1_, I_, J0_, (n_) + 3)
+        // Per wave, DMA issue order per K tile: XA XA W0 W0 W1 W1 XB XB (prologue and loop alike), so with vmcnt retiring in
+        // order: W1(t) has 10 younger loads at the top of phase 1, XB(t) 12 at phase 2, {XA, W0}(t+1) 12 at phase 4.
+        // A buffer is refilled (tile t+2) in the MFMA block of the phase AFTER the one whose top issued its last reads: every
+        // wave passes "s_waitcnt lgkmcnt(0); s_barrier" in between.
+        Frag wA[4], wB[4], xa0[4], xa1[4], xb0[4], xb1[4];
+        // fragment reads with the lane coordinates made opaque at every use: the LDS addresses are then recomputed (3 VALU
+        // ops per read) instead of ~20 loop-invariant addresses living in registers next to 96 fragment + 128 accumulator VGPRs
+        auto rd2 = [&](const char* base, int row0, Frag (&f)[4]) {
+            int r_ = fr, h_ = fh;
+            asm volatile("" : "+v"(r_), "+v"(h_));
+            const int sw_ = (r_ >> 1) & 7;
+            const char* a = base + (row0 + r_) * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                f[ks] = *reinterpret_cast<const Frag*>(a + (ks >> 1) * 16 * ROWB + ((((ks & 1) * 4 + h_) ^ sw_) << 4));
+        };
+        auto rdW2 = [&](const char* sb, int i, Frag (&f)[4]) { rd2(sb + (2 + i) * HT, wc * 32, f); };
+        auto rdX2 = [&](const char* sb, int h, int jj, Frag (&f)[4]) { rd2(sb + h * HT, wp * 64 + jj * 32, f); };
+        BIG_WAIT(12);                      // XA(0), W0(0) landed
+        BIG_BARRIER();
+        rdW2(smem, 0, wA); rdX2(smem, 0, 0, xa0); rdX2(smem, 0, 1, xa1);
+        __builtin_amdgcn_sched_barrier(0);
+        // one K tile; on entry w0 / xa hold W0(t) / XA(t), on exit w1 holds W0(t+1) and xa XA(t+1) (the caller swaps w0 and w1)
+        // single fragment reads, pinned BETWEEN the MFMAs of a block (a ds_read_b128 per MFMA gap is nearly free, MI355X_MICROARCH.md
+        // LDS): o0 / o1 = the lane's swizzled 16-byte chunk offsets of the two K halves, rp() = the lane's row in a half tile
+        int o0, o1;
+        auto rp = [&](const char* base, int row0) -> const char* {
+            int r_ = fr, h_ = fh;
+            asm volatile("" : "+v"(r_), "+v"(h_));
+            const int sw_ = (r_ >> 1) & 7;
+            o0 = (h_ ^ sw_) << 4;
+            o1 = ((4 + h_) ^ sw_) << 4;
+            return base + (row0 + r_) * ROWB;
+        };
+#define EESEG_RDF(dst_, a_, ks_) { dst_[ks_] = *reinterpret_cast<const Frag*>((a_) + ((ks_) >> 1) * 16 * ROWB + (((ks_) & 1) ? o1 : o0)); \
+            __builtin_amdgcn_sched_barrier(0); }
+        // one K tile; on entry w0 / xa hold W0(t) / XA(t), on exit w1 holds W0(t+1) and xa XA(t+1) (the caller swaps w0 and w1)
+        auto ktile = [&](int t, Frag (&w0)[4], Frag (&w1)[4]) {
+            const int s = t & 1;
+            const char* sb = smem + s * 4 * HT;
+            const char* sn = smem + (s ^ 1) * 4 * HT;
+            // ---- phase 1: read W1(t); multiply (W0, XA); refill XA, W0 of this stage
+            BIG_WAIT(10);
+            BIG_LGKM0();
+            BIG_BARRIER();
+            {
+                const char* aw = rp(sb + 3 * HT, wc * 32);
+                next_tile();                   // -> K tile t+2
+                __builtin_amdgcn_s_setprio(1);
+                EESEG_M16(w0, xa0, xa1, 0, 0, 0) EESEG_RDF(w1, aw, 0) EESEG_M16(w0, xa0, xa1, 0, 0, 1) dma1s(rx, 0, 0, voffA[0], soffA, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16(w0, xa0, xa1, 0, 0, 2) EESEG_RDF(w1, aw, 1) EESEG_M16(w0, xa0, xa1, 0, 0, 3) dma1s(rx, 0, 1, voffA[1], soffA, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16(w0, xa0, xa1, 0, 0, 4) EESEG_RDF(w1, aw, 2) EESEG_M16(w0, xa0, xa1, 0, 0, 5) dma1s(rw, 2, 0, (live ? voffW[0] : EESEG_OOB), soffW, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16(w0, xa0, xa1, 0, 0, 6) EESEG_RDF(w1, aw, 3) EESEG_M16(w0, xa0, xa1, 0, 0, 7) dma1s(rw, 2, 1, (live ? voffW[1] : EESEG_OOB), soffW, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16x4(w0, xa0, xa1, 0, 0, 8) EESEG_M16x4(w0, xa0, xa1, 0, 0, 12)
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // ---- phase 2: read XB(t); multiply (W1, XA); refill W1
+            BIG_WAIT(12);
+            BIG_LGKM0();
+            BIG_BARRIER();
+            {
+                const char* a0 = rp(sb + HT, wp * 64);
+                const char* a1 = a0 + 32 * ROWB;
+                __builtin_amdgcn_s_setprio(1);
+                EESEG_M16(w1, xa0, xa1, 1, 0, 0) EESEG_RDF(xb0, a0, 0) EESEG_M16(w1, xa0, xa1, 1, 0, 1) EESEG_RDF(xb0, a0, 1)
+                dma1s(rw, 3, 0, (live ? voffW[2] : EESEG_OOB), soffW, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16(w1, xa0, xa1, 1, 0, 2) EESEG_RDF(xb0, a0, 2) EESEG_M16(w1, xa0, xa1, 1, 0, 3) EESEG_RDF(xb0, a0, 3)
+                dma1s(rw, 3, 1, (live ? voffW[3] : EESEG_OOB), soffW, s); __builtin_amdgcn_sched_barrier(0);
+                EESEG_M16(w1, xa0, xa1, 1, 0, 4) EESEG_RDF(xb1, a1, 0) EESEG_M16(w1, xa0, xa1, 1, 0, 5) EESEG_RDF(xb1, a1, 1)
+                EESEG_M16(w1, xa0, xa1, 1, 0, 6) EESEG_RDF(xb1, a1, 2) EESEG_M16(w1, xa0, xa1, 1, 0, 7) EESEG_RDF(xb1, a1, 3)
+                EESEG_M16x4(w1, xa0, xa1, 1, 0, 8) EESEG_M16x4(w1, xa0, xa1, 1, 0, 12)
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // ---- phase 3: nothing to read; multiply (W1, XB); refill XB
+            BIG_LGKM0();
+            BIG_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+            EESEG_M16(w1, xb0, xb1, 1, 2, 0) EESEG_M16(w1, xb0, xb1, 1, 2, 1) dma1s(rx, 1, 0, voffA[2], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_M16(w1, xb0, xb1, 1, 2, 2) EESEG_M16(w1, xb0, xb1, 1, 2, 3) dma1s(rx, 1, 1, voffA[3], soffA, s); __builtin_amdgcn_sched_barrier(0);
+            EESEG_M16x4(w1, xb0, xb1, 1, 2, 4) EESEG_M16x4(w1, xb0, xb1, 1, 2, 8) EESEG_M16x4(w1, xb0, xb1, 1, 2, 12)
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 4: read W0(t+1) into w1's registers and XA(t+1); multiply (W0, XB)
+            BIG_WAIT(12);
+            BIG_BARRIER();
+            {
+                const char* aw = rp(sn + 2 * HT, wc * 32);
+                const char* a0 = sn + (aw - (sn + 2 * HT)) - (wc * 32) * ROWB + (wp * 64) * ROWB;     // same lane row, XA half tile
+                const char* a1 = a0 + 32 * ROWB;
+                __builtin_amdgcn_s_setprio(1);
+                EESEG_M16(w0, xb0, xb1, 0, 2, 0) EESEG_RDF(w1, aw, 0) EESEG_M16(w0, xb0, xb1, 0, 2, 1) EESEG_RDF(w1, aw, 1)
+                EESEG_M16(w0, xb0, xb1, 0, 2, 2) EESEG_RDF(w1, aw, 2) EESEG_M16(w0, xb0, xb1, 0, 2, 3) EESEG_RDF(w1, aw, 3)
+                EESEG_M16(w0, xb0, xb1, 0, 2, 4) EESEG_RDF(xa0, a0, 0) EESEG_M16(w0, xb0, xb1, 0, 2, 5) EESEG_RDF(xa0, a0, 1)
+                EESEG_M16(w0, xb0, xb1, 0, 2, 6) EESEG_RDF(xa0, a0, 2) EESEG_M16(w0, xb0, xb1, 0, 2, 7) EESEG_RDF(xa0, a0, 3)
+                EESEG_M16(w0, xb0, xb1, 0, 2, 8) EESEG_RDF(xa1, a1, 0) EESEG_M16(w0, xb0, xb1, 0, 2, 9) EESEG_RDF(xa1, a1, 1)
+                EESEG_M16(w0, xb0, xb1, 0, 2, 10) EESEG_RDF(xa1, a1, 2) EESEG_M16(w0, xb0, xb1, 0, 2, 11) EESEG_RDF(xa1, a1, 3)
+                EESEG_M16x4(w0, xb0, xb1, 0, 2, 12)
+                __builtin_amdgcn_s_setprio(0);
+            }
+        };
+        for (int t = 0; t < nk; t += 2) {
+            ktile(t, wA, wB);
+            if (t + 1 < nk) ktile(t + 1, wB, wA);
+        }
+        BIG_LGKM0();
+#undef EESEG_M16x4
+#undef EESEG_RDF
+#undef BIG_LGKM0
+        }
+#undef EESEG_M16
         BIG_WAIT(0);                       // trailing out-of-range DMAs still write (zeros) into LDS
         BIG_BARRIER();
     }
@@ -1736,6 +1870,7 @@ int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count o
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
 int g_conv_big_m16 = 1;          // EESEG_OPT_CONV_MFMA16: 1 (default) = the 256-tile kernel computes with v_mfma_f32_16x16x32_bf16, 0 = 32x32x16 (measured at 32 x 65 x 65: 3-7 % faster on every MFMA-bound layer, scripts/m16_bench.py)
+int g_conv_big_swp = 1;          // EESEG_OPT_CONV_SWP: software-pipelined K loop of the 16x16x32 form (default; same bits as the two-group loop, step 102.9 -> 101.8 ms)
 int g_conv_big_cg = 0;           // EESEG_OPT_CONV_COUT_GROUP: cout tiles an XCD works on at a time when a layer has more (0 = all; measured neutral: the merged ASPP data-gradient 3.18-3.27 ms for 0/1/2/4/8)
 
 // launch plan for the 256x256 kernel: full rounds of one tile per available CU, then the remainder split along K
@@ -1758,11 +1893,14 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
         const long long fit = workspace ? workspace_bytes / ((long long)rem * SLAB_FLOATS * 4) : 0;
         if (ksplit > fit) ksplit = (int)fit;
     }
-    const bool m16 = g_conv_big_m16 != 0;
+    const int form = g_conv_big_m16 ? (g_conv_big_swp ? 2 : 1) : 0;    // 0: 32x32x16, 1: 16x16x32, 2: 16x16x32 software-pipelined
+#define EESEG_LAUNCH_BIG(MODE_, grid_, args_) { \
+        if (form == 2) hipLaunchKernelGGL((conv_big_kernel<MODE_, true, true>), grid_, dim3(512), 0, st, args_); \
+        else if (form == 1) hipLaunchKernelGGL((conv_big_kernel<MODE_, true, false>), grid_, dim3(512), 0, st, args_); \
+        else hipLaunchKernelGGL((conv_big_kernel<MODE_, false, false>), grid_, dim3(512), 0, st, args_); }
     if (ksplit < 2) {
         p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr;
-        if (m16) hipLaunchKernelGGL((conv_big_kernel<0, true>), dim3(tiles), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv_big_kernel<0, false>), dim3(tiles), dim3(512), 0, st, p);
+        EESEG_LAUNCH_BIG(0, dim3(tiles), p)
         EESEG_LAUNCH_CHECK();
         return EESEG_OK;
     }
@@ -1771,19 +1909,17 @@ int launch_big(ConvP& p, long long M, hipStream_t st, void* workspace, long long
     p.tile_begin = rounds * cus;
     p.n_split_blocks = rem * ksplit;
     if (rounds > 0 && g_conv_big_merge) {      // one launch: K-range blocks first, whole tiles behind them
-        if (m16) hipLaunchKernelGGL((conv_big_kernel<2, true>), dim3(rem * ksplit + rounds * cus), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv_big_kernel<2, false>), dim3(rem * ksplit + rounds * cus), dim3(512), 0, st, p);
+        EESEG_LAUNCH_BIG(2, dim3(rem * ksplit + rounds * cus), p)
     } else {
         if (rounds > 0) {
             ConvP q = p;
             q.tile_begin = 0;
-            if (m16) hipLaunchKernelGGL((conv_big_kernel<0, true>), dim3(rounds * cus), dim3(512), 0, st, q);
-            else hipLaunchKernelGGL((conv_big_kernel<0, false>), dim3(rounds * cus), dim3(512), 0, st, q);
+            EESEG_LAUNCH_BIG(0, dim3(rounds * cus), q)
         }
-        if (m16) hipLaunchKernelGGL((conv_big_kernel<1, true>), dim3(rem * ksplit), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((conv_big_kernel<1, false>), dim3(rem * ksplit), dim3(512), 0, st, p);
+        EESEG_LAUNCH_BIG(1, dim3(rem * ksplit), p)
     }
-    if (m16) hipLaunchKernelGGL(conv_big_fixup_kernel<true>, dim3(rem * 8), dim3(256), 0, st, p);
+#undef EESEG_LAUNCH_BIG
+    if (form) hipLaunchKernelGGL(conv_big_fixup_kernel<true>, dim3(rem * 8), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv_big_fixup_kernel<false>, dim3(rem * 8), dim3(256), 0, st, p);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
@@ -1831,6 +1967,10 @@ extern "C" int eeseg_last_kernel(int which) {
 extern "C" int eeseg_set_option(int key, int value) {
     if (key == EESEG_OPT_CONV_PIPE && (value >= 0 && value <= 3)) {
         g_conv_pipe = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_SWP && (value == 0 || value == 1)) {
+        g_conv_big_swp = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_CONV_MFMA16 && (value == 0 || value == 1)) {
@@ -1925,6 +2065,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_PW_ALL: return g_conv_pw_all;
         case EESEG_OPT_CONV_COUT_GROUP: return g_conv_big_cg;
         case EESEG_OPT_CONV_MFMA16: return g_conv_big_m16;
+        case EESEG_OPT_CONV_SWP: return g_conv_big_swp;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;

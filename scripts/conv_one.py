@@ -12,6 +12,11 @@ if os.environ.get("EESEG_CONV_PIPE"):
     lib().eeseg_set_option(1, int(os.environ["EESEG_CONV_PIPE"]))
     if os.environ.get("EESEG_CONV_TAIL_MIN"):
         lib().eeseg_set_option(5, int(os.environ["EESEG_CONV_TAIL_MIN"]))
+if os.environ.get("EESEG_OPTS"):            # "key=value,key=value" -> eeseg_set_option (A/B of kernel forms under the counters)
+    from ee_semantic_segmentation_amd._lib import lib
+    for kv in os.environ["EESEG_OPTS"].split(","):
+        a, b = kv.split("=")
+        lib().eeseg_set_option(int(a), int(b))
 x = torch.randn(B, H, W, Cin, device="cuda").to(dtype)
 wt = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
 wf, wb = K.pack_weight(wt, dtype)

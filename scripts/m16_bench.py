@@ -32,9 +32,12 @@ for cin, cout, k, d in ((256, 256, 3, 2), (512, 512, 3, 4), (2048, 256, 3, 12), 
     fn = lambda: K.conv_fwd(x, wf, 1, pad, d, want_stats=True)
     row = []
     for m16 in (0, 1, 0, 1):
-        lib().eeseg_set_option(17, m16)
+        lib().eeseg_set_option(17, m16); lib().eeseg_set_option(19, 0)
         row.append(timeit(fn))
+    lib().eeseg_set_option(17, 1); lib().eeseg_set_option(19, 1)
+    swp = min(timeit(fn), timeit(fn))
+    lib().eeseg_set_option(19, 1)
     fl = 2.0 * B * H * H * cin * cout * k * k
     print(f"{k}x{k} {cin:5d}->{cout:4d} d{d:<2d}  32x32x16: {min(row[0], row[2]):8.1f} us ({fl / min(row[0], row[2]) / 1e6:6.0f} TF/s)   16x16x32: {min(row[1], row[3]):8.1f} us "
-          f"({fl / min(row[1], row[3]) / 1e6:6.0f} TF/s)   ratio {min(row[0], row[2]) / min(row[1], row[3]):.3f}", flush=True)
+          f"({fl / min(row[1], row[3]) / 1e6:6.0f} TF/s)   ratio {min(row[0], row[2]) / min(row[1], row[3]):.3f}   pipelined: {swp:8.1f} us ({fl / swp / 1e6:6.0f} TF/s)", flush=True)
 lib().eeseg_set_option(17, 1)

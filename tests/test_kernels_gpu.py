@@ -1021,6 +1021,9 @@ def test_conv_256_tile_cout_group_order():
         assert torch.equal(y, outs[0]), cg
 
 
+SWP_DEFAULT = 1      # default of EESEG_OPT_CONV_SWP (include/eeseg.h)
+
+
 @pytest.mark.parametrize("case", ["3x3-stats", "1x1-residual-relu", "atrous-tail"])
 def test_conv_256_tile_mfma_16x16x32(case):
     """EESEG_OPT_CONV_MFMA16: the 256-tile kernel built on v_mfma_f32_16x16x32_bf16 (four 16x16 accumulators per 32x32
@@ -1048,13 +1051,14 @@ def test_conv_256_tile_mfma_16x16x32(case):
     outs = {}
     try:
         lib().eeseg_set_option(13, 0)                  # keep pointwise layers off the 128x256 kernels for this comparison
-        for m16 in (0, 1):
-            assert lib().eeseg_set_option(17, m16) == 0
+        for m16 in (0, 1, 2):                          # 2 = 16x16x32 with the software-pipelined K loop (EESEG_OPT_CONV_SWP)
+            assert lib().eeseg_set_option(17, int(m16 > 0)) == 0 and lib().eeseg_set_option(19, int(m16 == 2)) == 0
             y, part = K.conv_fwd(xd, wf, 1, pad, dil, want_stats=stats, residual=rd, relu=relu)
             assert lib().eeseg_last_kernel(0) == 3                      # the 256-tile kernel ran
             outs[m16] = (y.clone(), None if part is None else K.reduce_partials(part).clone())
     finally:
         lib().eeseg_set_option(17, 1)
+        lib().eeseg_set_option(19, SWP_DEFAULT)
         lib().eeseg_set_option(13, 1280)
     for m16, (y, sums) in outs.items():
         close(nchw(y), want, tol(torch.bfloat16), f"mfma16={m16} vs torch")
@@ -1063,3 +1067,4 @@ def test_conv_256_tile_mfma_16x16x32(case):
             close(sums[0].cpu(), flat.sum(1).float(), 2e-3, f"mfma16={m16} sum")
             close(sums[1].cpu(), (flat * flat).sum(1).float(), 2e-3, f"mfma16={m16} sum of squares")
     close(outs[1][0], outs[0][0], 8e-3, "16x16x32 vs 32x32x16")
+    assert torch.equal(outs[2][0], outs[1][0]), "software-pipelined loop: same MFMAs in the same order, same bits"
