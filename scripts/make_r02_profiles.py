@@ -52,13 +52,16 @@ Reading.  The 3x3 stack the north-star target names holds the matrix pipes {u[2]
 time; nominal 2.4 GHz: MI355X_MICROARCH.md 'DVFS give-back'), so `roofline.frac` and `roofline.stack_3x3.frac` in the bench line are priced
 against the nominal peak, this table against the cycles the chip actually ran.
 
-**32x32x16 -> 16x16x32 (`EESEG_OPT_CONV_MFMA16`), same three forward layers, same counters, previous evidence run of this round vs this one:**
-kernel cycles 1.62e6 -> {rows[0][3]:.3g} (atrous 2048->256), 9.38e5 -> {rows[1][3]:.3g} (512->512), 2.88e5 -> {rows[2][3]:.3g} (256->256); pipe utilisation
-68.5 / 64.8 / 52.9 % -> {u[0]} / {u[1]} / {u[2]} %; wall time per call (`scripts/m16_bench.py`, same box) 985 -> 924, 541 -> 512, 167.8 -> 161.8 us.
-The 16x16 form needs ~9 % MORE cycles (an MFMA burst of the other wave group now takes half of the SIMD's issue slots instead of a quarter, so
-the LDS-read slot beside it stretches: `SQ_WAIT_INST_LDS` 4.2e7 -> 5.2e7) and still finishes 3-7 % EARLIER: the clock the chip holds
-under it is that much higher (1.62e6 cycles / 985 us = 1.65 GHz vs 1.77e6 / 924 us = 1.92 GHz on the atrous layer) - the guide's item 7, and the
-reason cycle counts alone would have rejected the change.
+**The three forms of `conv_big_kernel`'s K loop this round, same three forward layers, same counters** (atrous 2048->256 / 512->512 / 256->256):
+32x32x16 MFMAs, two wave groups half a phase apart (round 1): kernel cycles 1.62e6 / 9.38e5 / 2.88e5, pipe utilisation 68.5 / 64.8 / 52.9 %, waves
+parked 47 %, wall 985 / 541 / 167.8 us;  16x16x32 (`EESEG_OPT_CONV_MFMA16`): 1.77e6 / 1.01e6 / 3.05e5 cycles, 62.8 / 60.4 / 49.9 %, parked 46 %, wall
+924 / 512 / 161.8 us;  16x16x32 software-pipelined, eight waves in lockstep (`EESEG_OPT_CONV_SWP`, this table): {rows[0][3]:.3g} / {rows[1][3]:.3g} / {rows[2][3]:.3g} cycles,
+{u[0]} / {u[1]} / {u[2]} %, parked {100*rows[0][9]:.0f} %, wall ~930 / 517 / 155.5 us (`scripts/m16_bench.py`).
+The 16x16 shape needs ~9 % MORE cycles than 32x32 (twice the MFMA instructions: `SQ_ACTIVE_INST_ANY` 1.64e8 -> 1.95e8) and still finishes 3-7 %
+EARLIER: the clock the chip holds under it is that much higher (1.62e6 cycles / 985 us = 1.65 GHz vs 1.77e6 / 924 us = 1.92 GHz on the atrous layer) - the
+guide's 'DVFS give-back' item 7, and the reason cycle counts alone would have rejected the change.  The pipelined loop parks far less (`SQ_WAIT_ANY`
+3.8e8 -> 2.4e8) and stalls more at MFMA issue (`SQ_WAIT_INST_ANY` 2.5e8 -> 3.4e8): two very different schedules, the same ~64 % of the pipe cycles - what
+bounds the loop is the power-held clock and the issue port two MFMA-dense waves share, not where the waits sit.
 256->256 loses its 15 points to tile quantisation (32 x 65 x 65 pixels = 528.1 tiles of 256 on 256 CUs: two rounds + a K-split tail + the
 fix-up) and to the 7.5 us per-round fixed cost on a 36-K-tile loop.  The 1x1 layers are HBM-bound (SURVEY 8d): their figure of merit is
 bytes/s, not MFMA cycles - `roofline.by_shape` in the bench line prices every layer against its own max(flops/peak, bytes/BW).  The
