@@ -80,6 +80,11 @@ def cpu_baseline(arch, n_branches, C, img, B, seed):
                       f"{C} classes, {img}x{img}, B={B} ({dt:.1f} s)"}
 
 
+def _rccl_version():
+    from ee_semantic_segmentation_amd.comm import rccl_version
+    return rccl_version()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -91,18 +96,18 @@ class Run:
         from ee_semantic_segmentation_amd.from_deepv3_new import branchyDeepv3
         from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
         from ee_semantic_segmentation_amd.optim import SGD
-        from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, broadcast_parameters
+        from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, init_data_parallel
         self.arch, self.C, self.img, self.B, self.dtype, self.loss_name = arch, classes, img, batch, dtype, loss
         self.world = world
         torch.manual_seed(0)
         net = branchyDeepv3(None, f"deeplabv3_{arch}", branches, img, count_branches=False, num_classes=classes,
                             compute_dtype=torch.bfloat16 if dtype == "bf16" else torch.float32,
                             fused_outputs=True).to(dev)
-        # EESEG_FORCE_ALLREDUCE=1 (with RANK/WORLD_SIZE=1 set): a 1-rank RCCL group still issues every collective -
+        # N > 1: RCCL communicators through libeeseg (rendezvous over the gloo group), SyncBN, rank 0's weights everywhere.
+        # EESEG_FORCE_ALLREDUCE=1 (with RANK/WORLD_SIZE=1 set): a 1-rank communicator still issues every collective -
         # rehearses the N > 1 graph (SyncBN all-reduces, CE count, arena buckets) on one GPU
-        net.cfg.sync_bn = bool(sync_bn and (world > 1 or os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"))
         net.cfg.overlap_wgrad = args.overlap_wgrad
-        broadcast_parameters(net)
+        init_data_parallel(net, sync_bn=sync_bn)
         self.E = net.n_branches + 1
         if loss == "lovasz":
             from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
@@ -126,9 +131,9 @@ class Run:
         return self.runner(self.X, self.y)
 
     def workload(self):
-        loss = "per-exit CE (sum)" if self.loss_name == "ce" else "raw-logit Lovasz (sum over exits)"
-        return (f"DeepLabV3-{self.arch} {self.E} exits, {self.img}x{self.img}, {self.C} classes, global B="
-                f"{self.world * self.B} ({self.B}/GPU), {loss}, SGD momentum 0.9 wd 5e-4, {self.dtype}")
+        loss = "CE" if self.loss_name == "ce" else "Lovasz"
+        return (f"{self.dtype} DeepLabV3-{self.arch} E={self.E} {self.img}x{self.img} C={self.C} B={self.world * self.B}"
+                f" ({self.B}/GPU) {loss} SGD")
 
     def flop_per_image(self):
         return 3 * 2.0 * self.net.macs(self.img)                  # fwd + bwd = 3 x fwd, FLOP = 2 MAC
@@ -151,12 +156,19 @@ def timed(run, steps, warmup, world, rank, no_graph):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # per-step HIP events on the compute stream (median reported beside the contract's wall-clock mean)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        evs[i].record()
         last = run.step()
+    evs[steps].record()
     fence()
     dt = time.perf_counter() - t0
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    run.step_ms_median = per[len(per) // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
+    run.step_ms_min, run.step_ms_max = per[0], per[-1]
     return dt, float(last.item()), warmup_run
 
 
@@ -270,7 +282,9 @@ def main():
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # torch.distributed is the RENDEZVOUS only (the RCCL id, the timing maximum, barriers): gloo.  The data path is RCCL
+        # over xGMI called through libeeseg on streams this package owns (ee_semantic_segmentation_amd/comm.py)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
     from ee_semantic_segmentation_amd._lib import lib as _eelib
@@ -305,7 +319,7 @@ def main():
         prof_steps = args.roofline_steps
         prof = kernel_events(run, prof_steps)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -325,13 +339,24 @@ def main():
                 "config": {"workload": run.workload(), "global_batch": world * B, "batch_per_gpu": B,
                            "parallelism": f"dp{world}", "sync_bn": bool(run.net.cfg.sync_bn),
                            "hip_graph": bool(run.runner.graph is not None), "warmup_steps_run": warmup_run,
+                           "step_ms_hip_events": {"median": run.step_ms_median, "min": run.step_ms_min,
+                                                  "max": run.step_ms_max, "rank": 0},
+                           "collectives": ("RCCL %d via libeeseg, 2 communicators, package-owned lanes" % _rccl_version())
+                           if run.net.cfg.comm is not None else None,
                            "flop_per_image": flop_img, "loss_last_step": loss_val,
                            "splits": list(run.net.split_names)},
                 "roofline": roof}
     headline = (args.arch, args.branches, args.classes, args.img)
+    dp_comm = run.net.cfg.comm
+    run.runner.graph = None                       # the captured RCCL kernels go before their communicators
     del run, prof
     gc.collect()
     torch.cuda.empty_cache()
+    if dp_comm is not None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dp_comm.close()
 
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}
@@ -346,14 +371,18 @@ def main():
             del r2
             gc.collect()
             torch.cuda.empty_cache()
-            # the headline architecture in the fp32 parity mode (exact-fp32 MFMA; the mode the 1e-3 logit bar holds in)
-            bf = min(B, 8)
-            r3 = Run(headline[0], headline[1], headline[2], headline[3], bf, "f32", "ce", False, 1, 0, dev, args)
-            d3, l3, _ = timed(r3, 3, 0, 1, 1, True)
-            sec["f32_parity_mode"] = {"workload": r3.workload(), "value": bf * 3 / d3, "unit": "images/sec",
-                                      "ms_per_step": d3 / 3 * 1e3, "steps": 3, "hip_graph": False,
-                                      "whole_step_tflops": bf * 3 / d3 * r3.flop_per_image() / 1e12,
-                                      "peak_tflops": PEAK_F32_TFLOPS, "loss_last_step": l3}
+            # the headline workload itself in the fp32 parity mode (exact-fp32 MFMA: the mode the 1e-3 logit / exact-mask
+            # bar is held in) - same batch, same step count, same HIP-graph replay as the headline line
+            r3 = Run(headline[0], headline[1], headline[2], headline[3], B, "f32", "ce", False, 1, 0, dev, args)
+            d3, l3, _ = timed(r3, args.steps, args.warmup, 1, 1, args.no_graph)
+            sec["f32_parity_mode"] = {"workload": r3.workload(), "value": B * args.steps / d3, "unit": "images/sec",
+                                      "ms_per_step": d3 / args.steps * 1e3, "steps": args.steps,
+                                      "hip_graph": bool(r3.runner.graph is not None),
+                                      "step_ms_hip_events_median": r3.step_ms_median,
+                                      "whole_step_tflops": B * args.steps / d3 * r3.flop_per_image() / 1e12,
+                                      "peak_tflops": PEAK_F32_TFLOPS,
+                                      "frac_of_f32_matrix_peak": B * args.steps / d3 * r3.flop_per_image() / 1e12 / PEAK_F32_TFLOPS,
+                                      "loss_last_step": l3}
             del r3
             gc.collect()
             torch.cuda.empty_cache()

@@ -76,7 +76,7 @@ SIGNATURES = {
     "eeseg_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_sum_hw": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _i64, _vp]),
     "eeseg_broadcast_hw": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
-    "eeseg_dropout": (_i, [_vp, _vp, _i64, _f, _u64, _vp, _i, _vp]),
+    "eeseg_dropout": (_i, [_vp, _vp, _i64, _f, _u64, _vp, _i64, _i, _vp]),
     "eeseg_cast": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "eeseg_add_inplace": (_i, [_vp, _vp, _i64, _i, _vp]),
     "eeseg_copy2d": (_i, [_vp, _i64, _vp, _i64, _i64, _i64, _vp]),
@@ -104,6 +104,15 @@ SIGNATURES = {
     "eeseg_lovasz_workspace": (_i64, [_i64, _i]),
     "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _i64, _vp]),
     "eeseg_sgd_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
+    "eeseg_comm_available": (_i, [C.POINTER(_i)]),
+    "eeseg_comm_unique_id": (_i, [_vp]),
+    "eeseg_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "eeseg_comm_destroy": (_i, [_vp]),
+    "eeseg_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "eeseg_comm_check": (_i, [_vp]),
+    "eeseg_comm_all_reduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "eeseg_comm_all_gather": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "eeseg_comm_broadcast": (_i, [_vp, _vp, _i64, _i, _vp]),
 }
 
 _lib = None

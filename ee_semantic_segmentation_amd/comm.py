@@ -1,0 +1,145 @@
+"""Data-parallel collectives of the HIP path: RCCL through libeeseg's C ABI (``eeseg_comm_*``), enqueued on streams
+this package owns.
+
+The reference has no parallelism (``nn.DataParallel`` commented out at train_funcs.py:72-74); the exchange
+steps here are the build's own: gradient buckets, SyncBN statistics, the global CE valid-pixel count, the
+exact-Lovasz all-gather and the per-exit mIoU counters.
+
+``torch.distributed`` is used for the RENDEZVOUS only (the 128-byte RCCL id travels over the process group the caller
+initialised - gloo is enough) and for host-side bookkeeping.  The data path never creates a c10d ``Work``: c10d records
+each collective's end event on its own internal stream and polls it from a watchdog thread, and on HIP an event is
+"captured" as soon as the stream it was last recorded on is capturing - so a finished warm-up collective aborts the
+process when that internal stream is forked into the HIP-graph capture of the training step (round 2's
+hipErrorCapturedEvent; ``scripts/captured_event_repro.hip``).  Here a collective is ONE RCCL
+kernel on the stream given, eager or captured alike, and the fork / join edges are this package's own events.
+
+Two communicators per process group (``DataParallelComm``):
+  * ``grad``  - the large gradient buckets, on the lane ``lane_g`` (overlaps the rest of backward);
+  * ``stat``  - the small latency-bound collectives ([2,C] SyncBN pairs, [E] counts, logits all-gather), on the
+                compute stream or on ``lane_s`` (deferred SyncBN backward).
+A single communicator would serialise a [2,C] reduce behind a 64-MiB bucket.
+"""
+import ctypes as C
+import os
+
+import torch
+import torch.distributed as dist
+
+from ._lib import EesegError, check, lib
+
+_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float64: 2, torch.int32: 3, torch.int64: 4}
+SUM, AVG, MAX = 0, 1, 2
+
+
+def rccl_version():
+    v = C.c_int(0)
+    check(lib().eeseg_comm_available(C.byref(v)), "comm_available")
+    return v.value
+
+
+class Communicator:
+    """One RCCL communicator over the ranks of a torch.distributed group (rendezvous only)."""
+
+    def __init__(self, group=None, device=None):
+        if not dist.is_initialized():
+            raise EesegError("Communicator needs torch.distributed for the rendezvous (any backend; gloo is enough)")
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            check(lib().eeseg_comm_unique_id(buf), "comm_unique_id")
+            ident[0] = bytes(buf.raw)
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(ident, src=src, group=group)
+        handle = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(lib().eeseg_comm_create(ident[0], self.world, self.rank, C.byref(handle)), "comm_create")
+        self._h = handle
+
+    def _stream(self, stream):
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        return C.c_void_p(s.cuda_stream)
+
+    def _ok(self, t):
+        if not t.is_cuda or not t.is_contiguous():
+            raise EesegError("collectives take contiguous device tensors")
+        if self._h is None:
+            raise EesegError("communicator already closed")
+
+    def all_reduce(self, t, op=SUM, stream=None):
+        """In-place reduction of `t` over the ranks, enqueued on `stream` (default: the current stream)."""
+        self._ok(t)
+        check(lib().eeseg_comm_all_reduce(self._h, C.c_void_p(t.data_ptr()), t.numel(), _DTYPES[t.dtype], op,
+                                          self._stream(stream)), "comm_all_reduce")
+        return t
+
+    def all_gather(self, t, stream=None):
+        """-> [world, *t.shape] in rank order."""
+        self._ok(t)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        check(lib().eeseg_comm_all_gather(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          t.numel() * t.element_size(), self._stream(stream)), "comm_all_gather")
+        return out
+
+    def broadcast(self, t, root=0, stream=None):
+        self._ok(t)
+        check(lib().eeseg_comm_broadcast(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), root,
+                                         self._stream(stream)), "comm_broadcast")
+        return t
+
+    def check(self):
+        check(lib().eeseg_comm_check(self._h), "comm_check")
+
+    def close(self):
+        """Collective.  The device must be idle and every HIP graph that holds this communicator's kernels gone."""
+        h, self._h = self._h, None
+        if h is not None:
+            torch.cuda.synchronize(self.device)
+            check(lib().eeseg_comm_destroy(h), "comm_destroy")
+
+
+class Lane:
+    """A stream of this package beside the compute stream, with explicit fork / join edges (plain events: inside a
+    HIP-graph capture they become the graph's dependencies)."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.device = device
+        self.busy = False
+
+    def fork(self):
+        """Work enqueued on the lane from now on starts after everything the compute stream holds so far."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self.busy = True
+
+    def join(self):
+        """The compute stream waits for everything on the lane."""
+        if self.busy:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self.busy = False
+
+
+class DataParallelComm:
+    """The collectives a data-parallel replica of the network issues (module docstring).  ``engine.Config.comm``."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.stat = Communicator(group, device)
+        self.grad = Communicator(group, device)
+        self.world, self.rank, self.device = self.stat.world, self.stat.rank, self.stat.device
+        self.lane_g = Lane(self.device)
+        self.lane_s = Lane(self.device)
+
+    def close(self):
+        self.lane_g.join()
+        self.lane_s.join()
+        self.grad.close()
+        self.stat.close()
+
+
+def forced():
+    """EESEG_FORCE_ALLREDUCE=1: a 1-rank group still issues every collective (rehearsal on one GPU)."""
+    return os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"

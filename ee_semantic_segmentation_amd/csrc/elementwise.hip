@@ -868,7 +868,7 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {   // splitmix64 finalise
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long long n, float p, uint64_t seed0,
-                                                      const long long* __restrict__ step_dev) {
+                                                      const long long* __restrict__ step_dev, long long idx0) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const long long chunks = n / EPC;
     const float keep_scale = 1.f / (1.f - p);
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* x, T* y, long lon
         Vec<T> o;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const uint32_t h = mix32(seed ^ (uint64_t)(i * EPC + e) * 0xD6E8FEB86659FD93ull) >> 8;
+            const uint32_t h = mix32(seed ^ (uint64_t)(idx0 + i * EPC + e) * 0xD6E8FEB86659FD93ull) >> 8;
             o.e[e] = from_f32<T>(h >= thr ? to_f32(v.e[e]) * keep_scale : 0.f);
         }
         st16(y + i * EPC, o);
@@ -1451,8 +1451,8 @@ extern "C" int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW
 }
 
 extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step_dev,
-                             int dtype, void* stream) {
-    EESEG_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f, EESEG_ERR_ARG, "dropout: bad argument");
+                             int64_t index_offset, int dtype, void* stream) {
+    EESEG_CHECK(x && y && n > 0 && p >= 0.f && p < 1.f && index_offset >= 0, EESEG_ERR_ARG, "dropout: bad argument");
     const int epc = 16 / eeseg_dtype_size(dtype);
     EESEG_CHECK(n % epc == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, EESEG_ERR_ARG,
                 "dropout: n must be a multiple of %d and pointers 16-byte aligned", epc);
@@ -1460,10 +1460,10 @@ extern "C" int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_
     const int g = ew_grid(n / epc);
     if (dtype == EESEG_BF16)
         hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long long)n,
-                           p, seed, (const long long*)step_dev);
+                           p, seed, (const long long*)step_dev, (long long)index_offset);
     else
         hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, (long long)n, p,
-                           seed, (const long long*)step_dev);
+                           seed, (const long long*)step_dev, (long long)index_offset);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -16,12 +16,15 @@ from torch import optim, utils
 from . import from_deepv3_new as dv3
 from .eval_mIoU import mIoU_evaluator
 from .optim import SGD
+from .parallel import ShardSampler, dp_info, eval_shard, init_data_parallel
 from .train_funcs import train
 
 get_metric = {"mIoU": mIoU_evaluator}          # module_variables.py:112
 
 
 def _say(msg, use_file):
+    if torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+        return                                   # data parallel: rank 0 keeps the log
     if use_file:
         with open(use_file, "a") as f:
             f.write(msg)
@@ -89,8 +92,12 @@ def train_deepv3(net, num_epochs, kwargs):
         num_workers = kwargs["def_nworkers"](b_size) if "def_nworkers" in kwargs else 0
         p_factor = kwargs["def_prefetch"](b_size) if "def_prefetch" in kwargs and num_workers else None
         scheduler, ret_lr = None, False
-        if use_scheduler and kwargs.get("scheduler_patience"):   # deepv3_funcs.py:139-146
-            sp = kwargs["scheduler_patience"]
+        # deepv3_funcs.py:53-57: 's_patience', overridden by int(patience * .5) whenever early stopping has a patience
+        # ('scheduler_patience' is kept as an alias of this package's round-2 key)
+        sp = kwargs.get("s_patience", kwargs.get("scheduler_patience")) if use_scheduler else None
+        if use_scheduler and patience:
+            sp = int(patience * .5)
+        if use_scheduler and sp:                                 # deepv3_funcs.py:139-146
             floors = lr * .01 if not kwargs.get("base_lr") else \
                 [kwargs["base_lr"] * .01 for _ in range(len(optimizer.param_groups) - 1)] + [lr * .01]
             scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=.75, mode="min" if minimize else "max",
@@ -105,19 +112,34 @@ def train_deepv3(net, num_epochs, kwargs):
             else:
                 scheduler = optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda k: (1 - k / num_epochs) ** .9)
             ret_lr = True
-        train_loader = utils.data.DataLoader(train_set, batch_size=b_size, shuffle=True, num_workers=num_workers,
-                                             drop_last=False, prefetch_factor=p_factor, pin_memory=True)
+        # `b_size` is the GLOBAL batch (the reference's single device sees all of it, main_bradeepv3.py:119); under data
+        # parallelism rank r loads the r-th b_size/world slice of every global batch (parallel.ShardSampler; the ragged
+        # last batch is dropped there when world > 1, kept like the reference's drop_last=False otherwise)
+        world, rank = dp_info(net)
+        sampler = ShardSampler(len(train_set), b_size, world, rank, seed=kwargs.get("seed", 0))
+        train_loader = utils.data.DataLoader(train_set, batch_size=b_size // world, sampler=sampler,
+                                             num_workers=num_workers, drop_last=False, prefetch_factor=p_factor,
+                                             pin_memory=True)
         aux = train(net, train_loader, loss, val_iter=val_loader, num_epochs=num_epochs, updater=optimizer,
                     patience=patience, saveat=saveat, start_from=start_from or None, device=device,
                     use_file=use_file, verbose=True, metrics=train_metrics, name=net_id, scheduler=scheduler,
                     min_lr=min_lr, ret_lr=ret_lr, minimize=minimize, n_branches=n_branches,
-                    nout_channels=kwargs["nout_channels"])
+                    nout_channels=kwargs["nout_channels"], use_graph=kwargs.get("use_graph", True),
+                    save_last=kwargs.get("save_last"))
         net_res = {k: v + aux[k] for k, v in net_res.items()} if net_res else aux      # B-10 fixed
-    DataFrame.from_dict({k: v for k, v in net_res.items()}).to_csv(os.path.join(res_dir, f"{net_id}_tr.csv"),
-                                                                   index=False)
+    if dp_info(net)[1] == 0:
+        DataFrame.from_dict({k: v for k, v in net_res.items()}).to_csv(os.path.join(res_dir, f"{net_id}_tr.csv"),
+                                                                       index=False)
     save_dict = torch.load(saveat, weights_only=True)
     net.load_state_dict(save_dict["model_state_dict"])
-    torch.save(net.state_dict(), save_model)       # state_dict, not a pickled module (safe to reload)
+    kwargs["best_epoch"] = save_dict.get("epoch")      # which epoch's weights the final model holds (identical on every rank)
+    kwargs["tracker"] = {k: list(v) for k, v in net_res.items()}
+    if dp_info(net)[0] > 1:
+        torch.distributed.barrier()               # every rank has read the best checkpoint before rank 0 replaces the file
+    if dp_info(net)[1] == 0:
+        torch.save(net.state_dict(), save_model)       # state_dict, not a pickled module (safe to reload)
+    if dp_info(net)[0] > 1:
+        torch.distributed.barrier()
     _say(f"--> Finished training {net_id} (time: {dttm.datetime.now().strftime('%m/%d %H:%M:%S')})\n", use_file)
     return save_model
 
@@ -137,6 +159,11 @@ def eval_deepv3(kwargs):
                             branch_params=kwargs.get("branch_params"), num_classes=C,
                             compute_dtype=kwargs.get("compute_dtype", torch.float32))
     net.to(device)
+    # data parallel: under torch.distributed.run (main_bradeepv3 initialises the process group) every rank
+    # builds the same network, takes rank 0's weights, BatchNorm becomes SyncBN and the collectives go over RCCL
+    if torch.distributed.is_initialized() and device.type == "cuda":
+        init_data_parallel(net, sync_bn=True, transport=kwargs.get("dp_transport"))
+    world, rank = dp_info(net)
     if n_branches and n_branches != net.n_branches:
         n_branches = net.n_branches
         kwargs["loss"].update_n(n_branches)
@@ -145,18 +172,25 @@ def eval_deepv3(kwargs):
              f"branches\n", use_file)
     final_model = os.path.join(saveat, name + ".pth")
     if kwargs.get("num_epochs", 0):
-        val_loader = utils.data.DataLoader(kwargs["val_set"], batch_size=5, shuffle=False, num_workers=0,
-                                           drop_last=False)
+        val_loader = utils.data.DataLoader(eval_shard(kwargs["val_set"], world, rank), batch_size=5, shuffle=False,
+                                           num_workers=0, drop_last=False)
         kwargs |= {"val_loader": val_loader, "save_model": final_model}
         final_model = train_deepv3(net, kwargs["num_epochs"], kwargs)
         net.load_state_dict(torch.load(final_model, weights_only=True))
     else:
-        torch.save(net.state_dict(), final_model)
+        if rank == 0:
+            torch.save(net.state_dict(), final_model)
     net.to(device)
     net.eval()
-    test_loader = utils.data.DataLoader(kwargs["test_set"], batch_size=5, shuffle=False, num_workers=0,
-                                        drop_last=False)
-    aux_res = mIoU_evaluator(net, n_branches + 1, C, test_loader, device)
+    test_loader = utils.data.DataLoader(eval_shard(kwargs["test_set"], world, rank), batch_size=5, shuffle=False,
+                                        num_workers=0, drop_last=False)
+    aux_res = mIoU_evaluator(net, n_branches + 1, C, test_loader, device)      # counters summed over the ranks
+    kwargs["test_result"] = dict(aux_res)
+    if getattr(net.cfg, "comm", None) is not None:      # collective teardown; the training graphs died with train()
+        net.cfg.comm.close()
+        net.cfg.comm = None
+    if rank != 0:
+        return final_model
     res = defaultdict(list)
     res["net_id"].append(name)
     for key, val in aux_res.items():

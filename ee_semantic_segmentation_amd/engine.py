@@ -45,19 +45,21 @@ class Config:
         self._side = None                    # the two kernels fill each other's partially filled last block round
         self._side_busy = False
         self._side_keep = []                 # tensors the side stream still reads (freed after the join)
-        # SyncBN backward, opt-in (EESEG_DEFER_WGRAD=1): the weight gradient of layer L is held back and issued right after
-        # layer L-1's statistics all-reduce has been launched ASYNCHRONOUSLY, so it runs while that (latency-bound) collective
-        # is in flight.  Off by default: unmeasurable with one rank, and one run of the 1-rank rehearsal died in RCCL's watchdog
-        # (hipErrorCapturedEvent on an event query) with the asynchronous form - the default keeps the synchronous call
-        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "0") == "1"
+        # SyncBN backward: the weight gradient of layer L is held back and issued right after layer L-1's statistics
+        # all-reduce has been launched on the side lane (comm.DataParallelComm.lane_s), so it runs while that latency-bound
+        # collective is in flight; in the captured graph the two are parallel branches.  Same mechanism as the gradient
+        # buckets (RCCL through the C ABI on a package-owned stream).  EESEG_DEFER_WGRAD=0: A/B switch (collective on the
+        # compute stream, weight gradient in place).
+        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "1") != "0"
         self._deferred = None
+        self.comm = None                     # comm.DataParallelComm: RCCL through libeeseg (parallel.init_data_parallel)
 
     def world(self):
         """Number of ranks BatchNorm statistics are reduced over (1 = local BN).  With
         EESEG_FORCE_ALLREDUCE=1 a 1-rank group still issues the collectives (rehearsal on one GPU)."""
-        if not (self.sync_bn and dist.is_initialized()):
+        if not self.sync_bn:
             return 1
-        return dist.get_world_size(self.group)
+        return self.dp_world()
 
     def sync_active(self):
         return self.sync_bn and self.dp_active()
@@ -65,45 +67,78 @@ class Config:
     def dp_world(self):
         """Ranks of the data-parallel group (independent of sync_bn): the CE valid-pixel count and the exact
         Lovasz mode are always global over it."""
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def dp_active(self):
         import os
-        return dist.is_initialized() and (
-            dist.get_world_size(self.group) > 1 or os.environ.get("EESEG_FORCE_ALLREDUCE") == "1")
+        forced = os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"
+        if self.comm is not None:
+            return self.comm.world > 1 or forced
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or forced)
 
     def dp_rank(self):
+        if self.comm is not None:
+            return self.comm.rank
         return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def _no_transport(self, t):
+        from ._lib import EesegError
+        return EesegError(
+            "a data-parallel collective on a device tensor needs the RCCL communicator of the HIP path: call "
+            "parallel.init_data_parallel(net) after torch.distributed.init_process_group (any backend).  "
+            "torch.distributed's own NCCL process group is deliberately not used for the data path (DESIGN.md section 7)")
 
     def all_gather(self, t):
         """-> [world, *t.shape]: `t` of every rank of the data-parallel group, in rank order."""
         if self.gatherer is not None:
             return self.gatherer(t, self.group)
+        if self.comm is not None:
+            return self.comm.stat.all_gather(t.contiguous())
+        if t.is_cuda:
+            raise self._no_transport(t)
         out = torch.empty((self.dp_world(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
     def all_reduce(self, t):
-        """Sum `t` over the data-parallel group in place.  `collective` (callable(t, group)) replaces
-        torch.distributed's call; the world-2 parity tests use it to stage device tensors through gloo."""
+        """Sum `t` over the data-parallel group in place, on the compute stream.  Transports: the RCCL communicator
+        (`comm`, the product), the `collective` test hook (callable(t, group): the world-2 parity tests stage device
+        tensors through gloo), or torch.distributed itself for HOST tensors (gloo; CPU tests of the host algebra)."""
         if self.collective is not None:
             self.collective(t, self.group)
+        elif self.comm is not None:
+            self.comm.stat.all_reduce(t)
+        elif t.is_cuda:
+            raise self._no_transport(t)
         else:
             dist.all_reduce(t, group=self.group)
         return t
 
     def all_reduce_begin(self, t):
-        """Launch the in-place sum of `t`; -> handle for all_reduce_end.  Kernels issued on the current stream between
-        the two calls run beside the collective (RCCL's own stream; parallel branches of a captured graph)."""
-        if self.collective is not None:
-            self.collective(t, self.group)
+        """Launch the in-place sum of `t` on the side lane; -> token for all_reduce_end.  Kernels issued on the compute
+        stream between the two calls run beside the collective (parallel branches of a captured graph)."""
+        if self.collective is not None or self.comm is None:
+            self.all_reduce(t)
             return None
-        return dist.all_reduce(t, group=self.group, async_op=True)
+        lane = self.comm.lane_s
+        lane.fork()
+        self.comm.stat.all_reduce(t, stream=lane.stream)
+        return lane
 
     @staticmethod
-    def all_reduce_end(work):
-        if work is not None:
-            work.wait()                      # stream-level: the current stream waits for the collective
+    def all_reduce_end(lane):
+        if lane is not None:
+            lane.join()                      # stream-level: the compute stream waits for the collective
+
+    def reset_transients(self):
+        """Drop everything a failed / abandoned step may have left behind (held-back weight gradient, side-stream state)."""
+        self._deferred = None
+        self._side_busy = False
+        self._side_keep = []
+        if self.comm is not None:
+            self.comm.lane_g.busy = self.comm.lane_s.busy = False
 
     def run_deferred(self):
         """Issue the weight gradient that conv_bn_bwd held back (no-op when there is none)."""
@@ -653,7 +688,8 @@ def head_fwd(cfg, x, head, train, frozen=False):
         pdrop = 0.0 if frozen else proj[3].p
         if pdrop > 0:
             seed = cfg.next_seed()
-            pr_d = K.dropout(pr, pdrop, seed, cfg.step_dev(pr.device))
+            # data parallel: rank r draws the r-th slice of the whole batch's mask (eeseg_dropout index_offset)
+            pr_d = K.dropout(pr, pdrop, seed, cfg.step_dev(pr.device), cfg.dp_rank() * pr.numel() if cfg.dp_active() else 0)
         else:
             pr_d = pr
         q, stq = conv_bn_fwd(cfg, pr_d, head.conv3, head.bn3, True, frozen=frozen)
@@ -706,7 +742,8 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
     # 3x3 conv + BN + ReLU
     dpr_d, _, dw3, dg3, db3 = conv_bn_bwd(cfg, stq, dq, head.conv3, head.bn3)
     proj = aspp.project
-    dpr = K.dropout(dpr_d, proj[3].p, seed, cfg.step_dev(dpr_d.device)) if seed is not None else dpr_d
+    dpr = K.dropout(dpr_d, proj[3].p, seed, cfg.step_dev(dpr_d.device),
+                    cfg.dp_rank() * dpr_d.numel() if cfg.dp_active() else 0) if seed is not None else dpr_d
     dcat, _, dwj, dgj, dbj = conv_bn_bwd(cfg, stj, dpr, proj[0], proj[1])
     grads_convs = []
     dx = dx_init if head.pre is None else None

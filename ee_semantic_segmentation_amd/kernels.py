@@ -570,11 +570,11 @@ def broadcast_hw(x, out, scale=1.0, accumulate=False):
     return out
 
 
-def dropout(x, p, seed, step_dev=None):
+def dropout(x, p, seed, step_dev=None, index_offset=0):
     assert x.is_contiguous()
     y = torch.empty_like(x)
-    check(lib().eeseg_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _p(step_dev), _dt(x),
-                              _stream()), "eeseg_dropout")
+    check(lib().eeseg_dropout(_p(x), _p(y), x.numel(), float(p), int(seed) & (2 ** 64 - 1), _p(step_dev),
+                              int(index_offset), _dt(x), _stream()), "eeseg_dropout")
     return y
 
 

@@ -37,8 +37,24 @@ def build_parser(default_loss):
     return p
 
 
+def init_distributed():
+    """Under `python -m torch.distributed.run --nproc-per-node N -m ee_semantic_segmentation_amd.main_bradeepv3 ...`: bind
+    this process to its GPU and join the job BEFORE any GPU call.  torch.distributed is the rendezvous (gloo); the
+    collectives of the training step go over RCCL through libeeseg (parallel.init_data_parallel, called by eval_deepv3).
+    -> (world, rank, local_rank)."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    return world, rank, local_rank
+
+
 def main(default_loss="lovasz", argv=None):
     args = build_parser(default_loss).parse_args(argv)
+    world, rank, local_rank = init_distributed()
     n_branches, lr = args.n_branches, args.lr
     base_lr = args.base_lr or (lr if n_branches else 0)
     dataset = "voc_seg"
@@ -46,7 +62,7 @@ def main(default_loss="lovasz", argv=None):
     og_dir = os.getcwd()
     r_dir = os.path.join(og_dir, f"{dataset}_results")
     try:
-        os.makedirs(r_dir)
+        os.makedirs(r_dir, exist_ok=True)
     except OSError as err:
         if err.errno != errno.EEXIST:
             raise
@@ -58,7 +74,7 @@ def main(default_loss="lovasz", argv=None):
     else:
         loss = BSL.LovaszSoftmax(classes="present", ignore=C, n_branches=n_branches)
     dts_info = {
-        "device": torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))),
+        "device": torch.device("cuda", local_rank),
         "name": args.Name, "main_dir": og_dir, "n_procs": 1, "n_rep": 1, "res_dir": r_dir,
         "input_dim": args.dim, "train_set": train_set, "val_set": val_set, "test_set": test_set,
         "use_file": use_file, "def_prefetch": lambda x: 2, "def_nworkers": lambda x: 0,
@@ -72,9 +88,12 @@ def main(default_loss="lovasz", argv=None):
     }
     ret = eval_deepv3(dts_info)
     msg = f"Finished training. model is saved @ {ret}"
-    with open(use_file, "a") as f:
-        f.write(msg + "\n" + "-" * 20 + "\n")
-    print(msg)
+    if rank == 0:
+        with open(use_file, "a") as f:
+            f.write(msg + "\n" + "-" * 20 + "\n")
+        print(msg)
+    if world > 1:
+        torch.distributed.barrier()
     return ret
 
 

@@ -1,15 +1,17 @@
-"""Data-parallel training over the GPUs of one node: one process per GPU,
-``torch.distributed`` (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL over xGMI
+called through libeeseg's C ABI (``comm.DataParallelComm``); ``torch.distributed`` does the
+rendezvous (any backend - gloo is enough) and the CPU tests.
 
 The reference has no parallelism at all (nn.DataParallel is commented
 out at train_funcs.py:72-74), so this is new: gradients are all-reduced in
 buckets that fill in reverse-layer order while backward is still running
-(classifier / deep heads first), each bucket flattened by one kernel and reduced
-asynchronously on RCCL's stream; ``finish()`` makes the compute stream wait before
-the optimizer step.  xGMI is point-to-point, so buckets are large (default 64 MiB)
-- few, big collectives keep every link busy instead of paying per-call latency.
-BatchNorm statistics (engine.Config.sync_bn) and the CE valid-pixel count are
-all-reduced inside the respective layers.
+(classifier / deep heads first); a bucket is a plain slice of the gradient arena,
+reduced on the package's own lane stream beside the rest of backward; ``finish()``
+makes the compute stream wait before the optimizer step.  xGMI is point-to-point, so
+buckets are large (default 64 MiB) - few, big collectives keep every link busy instead
+of paying per-call latency.  BatchNorm statistics (engine.Config.sync_bn) and the CE
+valid-pixel count are all-reduced inside the respective layers.  No c10d ``Work`` is
+ever created for a device tensor: comm.py says why.
 """
 import os
 
@@ -27,7 +29,12 @@ def _flat_view(t):
 
 
 class GradReducer:
+    """Autograd-hook bucket reducer over torch.distributed for HOST tensors (gloo): the CPU rehearsal of the bucket
+    bookkeeping.  The HIP path uses ArenaReducer (RCCL through libeeseg); device parameters are refused."""
+
     def __init__(self, module, bucket_bytes=64 << 20, group=None, average=True):
+        if any(p.is_cuda for p in module.parameters()):
+            raise RuntimeError("GradReducer is the CPU/gloo rehearsal; on the GPU use net.enable_grad_arena() + ArenaReducer")
         self.module, self.group, self.average = module, group, average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         params = [p for p in module.parameters() if p.requires_grad]
@@ -94,13 +101,108 @@ class GradReducer:
 
 
 def broadcast_parameters(module, src=0, group=None):
-    """Make every rank start from rank `src`'s weights and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    """Make every rank start from rank `src`'s weights and buffers.  Device tensors travel over the network's RCCL
+    communicator (engine.Config.comm), host tensors over torch.distributed."""
+    cfg = getattr(module, "cfg", None)
+    comm = getattr(cfg, "comm", None)
+    if comm is None and (not dist.is_initialized() or dist.get_world_size(group) == 1):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             flat = _flat_view(t.data)
-            dist.broadcast(flat, src, group=group)
+            if comm is not None and flat.is_cuda:
+                if comm.world > 1:
+                    comm.stat.broadcast(flat, src)
+            elif flat.is_cuda and getattr(cfg, "collective", None) is not None:
+                host = flat.cpu()                  # test transport (gloo): staged through the host, once, at start-up
+                dist.broadcast(host, src, group=group)
+                flat.copy_(host)
+            elif flat.is_cuda:
+                raise RuntimeError("device parameters need parallel.init_data_parallel(net) before broadcast_parameters")
+            else:
+                dist.broadcast(flat, src, group=group)
+
+
+def init_data_parallel(net, group=None, sync_bn=True, broadcast=True, transport=None):
+    """Attach the data-parallel machinery to `net` (one call per process, after torch.distributed.init_process_group and
+    torch.cuda.set_device): the RCCL communicators (rendezvous over `group`), SyncBN so that BatchNorm sees the global
+    batch like the reference's single device does (main_bradeepv3.py:119 trains at batch 32), and identical start
+    weights.  -> the DataParallelComm, or None when there is nothing to do (no process group / one rank).
+
+    `transport=(collective, gatherer)`: test hook - callables (tensor, group) used instead of the RCCL communicators
+    (engine.Config.collective / .gatherer; the world-2 tests on ONE GPU stage device tensors through gloo, where two
+    ranks cannot share an RCCL communicator)."""
+    from . import comm as C_
+    if not dist.is_initialized():
+        return None
+    world = dist.get_world_size(group)
+    if world == 1 and not C_.forced():
+        return None
+    cfg = net.cfg
+    cfg.group = group
+    if transport is not None:
+        cfg.collective, cfg.gatherer = transport
+    elif cfg.comm is None:
+        cfg.comm = C_.DataParallelComm(group, next(net.parameters()).device)
+    cfg.sync_bn = bool(sync_bn)
+    if broadcast:
+        broadcast_parameters(net, 0, group)
+    return cfg.comm
+
+
+def dp_info(net=None):
+    """(world, rank) of the data-parallel job this process belongs to; (1, 0) without one."""
+    cfg = getattr(net, "cfg", None)
+    if cfg is not None and (cfg.comm is not None or cfg.collective is not None):
+        return cfg.dp_world(), cfg.dp_rank()
+    if dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Index stream of ONE rank for a DataLoader(batch_size = global_batch // world) (SURVEY 8e "DistributedSampler-style
+    seeding"): one permutation of the data set per (seed, epoch), identical on every rank; global batch k is
+    perm[k*B:(k+1)*B] - exactly what a single process with batch B would train on - and rank r takes the r-th
+    contiguous b-sample slice of it.  With more than one rank the ragged last global batch is dropped: SyncBN's
+    count * world, the averaging reducer and the exact-Lovasz all-gather assume equal shards on every rank."""
+
+    def __init__(self, n, global_batch, world=1, rank=0, seed=0, shuffle=True):
+        if global_batch % world:
+            raise ValueError(f"global batch {global_batch} is not divisible by {world} ranks")
+        self.n, self.B, self.world, self.rank, self.seed, self.shuffle = n, global_batch, world, rank, seed, shuffle
+        self.b = global_batch // world
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _order(self):
+        if not self.shuffle:
+            return list(range(self.n))
+        g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
+        return torch.randperm(self.n, generator=g).tolist()
+
+    def __iter__(self):
+        order = self._order()
+        full = self.n // self.B
+        for k in range(full):
+            lo = k * self.B + self.rank * self.b
+            yield from order[lo:lo + self.b]
+        if self.world == 1:                        # single process: keep the reference's drop_last=False tail
+            yield from order[full * self.B:]
+
+    def __len__(self):
+        full = self.n // self.B
+        return full * self.b + (self.n - full * self.B if self.world == 1 else 0)
+
+
+def eval_shard(dataset, world, rank):
+    """Evaluation under data parallelism: rank r scores samples r, r + world, ... and the per-exit counters are summed
+    over the ranks once per evaluation (eval_mIoU.mIoU_evaluator); shards may be ragged."""
+    if world == 1:
+        return dataset
+    return torch.utils.data.Subset(dataset, list(range(rank, len(dataset), world)))
 
 
 class ArenaReducer:
@@ -121,10 +223,15 @@ class ArenaReducer:
         self.arena = net.cfg.arena
         if self.arena is None:
             raise RuntimeError("call net.enable_grad_arena() first")
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.comm = getattr(net.cfg, "comm", None)
+        if self.comm is not None:
+            self.world = self.comm.world
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # EESEG_FORCE_ALLREDUCE=1: issue the collectives even in a 1-rank group (lets a single
         # GPU exercise the RCCL-inside-HIP-graph path the multi-GPU bench relies on)
-        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("EESEG_FORCE_ALLREDUCE") == "1")
+        forced = os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"
+        self.active = self.world > 1 or (forced and (self.comm is not None or dist.is_initialized()))
         self.buckets = []            # (first unit, last unit, start, end)
         u0, start = 0, 0
         for u, (a, b) in enumerate(self.arena.unit_ranges):
@@ -133,7 +240,7 @@ class ArenaReducer:
                 u0, start = u + 1, b
         self._done = set()
         self._next = 0
-        self._works = []
+        self._host_div = []
         if self.active:
             self.cfg.on_unit_done = self._unit_done
 
@@ -159,11 +266,18 @@ class ArenaReducer:
         hook = getattr(self.cfg, "collective", None)
         if hook is not None:                        # test hook (engine.Config.collective): synchronous sum
             hook(seg, self.group)
-            self._works.append((None, seg, dist.ReduceOp.SUM))
-            return
-        nccl = dist.get_backend(self.group) == "nccl"
-        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
-        self._works.append((dist.all_reduce(seg, op=op, group=self.group, async_op=True), seg, op))
+            self._host_div.append(seg)
+        elif self.comm is not None:
+            # the bucket's units are complete on the compute stream: fork the lane there, reduce on the lane
+            from .comm import AVG, SUM
+            lane = self.comm.lane_g
+            lane.fork()
+            self.comm.grad.all_reduce(seg, AVG if self.average else SUM, stream=lane.stream)
+        elif seg.is_cuda:
+            raise RuntimeError("device gradients need parallel.init_data_parallel(net) (RCCL through libeeseg)")
+        else:                                       # host arena (gloo rehearsal of the bucket schedule)
+            dist.all_reduce(seg, group=self.group)
+            self._host_div.append(seg)
 
     def finish(self):
         if not self.active:
@@ -172,17 +286,20 @@ class ArenaReducer:
             _, _, a, b = self.buckets[self._next]
             self._launch(a, b)
             self._next += 1
-        for work, seg, op in self._works:
-            if work is not None:
-                work.wait()
-            if self.average and op == dist.ReduceOp.SUM:
+        if self.comm is not None:
+            self.comm.lane_g.join()                 # the optimizer step waits for the last bucket
+        for seg in self._host_div:
+            if self.average:
                 seg.div_(self.world)
         if self._reserved:
             self._plan_cus(256)
             self._reserved = False
+        self.reset()
+
+    def reset(self):
         self._done.clear()
         self._next = 0
-        self._works = []
+        self._host_div = []
 
 
 class GraphedTrainStep:
@@ -234,18 +351,18 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                # thread_local: the RCCL watchdog thread keeps polling the events of the warm-up steps' collectives
-                # (hipEventQuery); under the default global capture mode such a poll during the capture is an error
-                # that aborts the process
+                # thread_local: other threads of the host process (a c10d watchdog when the caller's rendezvous group is
+                # NCCL, data-loader pin threads) may call HIP APIs that are illegal during a GLOBAL-mode capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self.loss = self._eager(self.X, self.y)
             except Exception as exc:                # e.g. a collective that cannot be captured
                 import warnings
                 warnings.warn(f"HIP-graph capture of the training step failed ({exc!r}); running eagerly")
                 torch.cuda.synchronize()
-                if self.reducer is not None and hasattr(self.reducer, "_works"):
-                    self.reducer._works, self.reducer._next = [], 0
-                    getattr(self.reducer, "_done", set()).clear()
+                if self.reducer is not None:
+                    self.reducer.reset()
+                # a closure held back by conv_bn_bwd during the aborted capture points into the graph's private pool
+                self.net.cfg.reset_transients()
                 for b, n in zip(self._bns, before):
                     b._pending_batches = n
                 self.use_graph = False

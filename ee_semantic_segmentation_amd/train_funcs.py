@@ -12,10 +12,10 @@ from copy import deepcopy
 import numpy as np
 import torch
 
-from .parallel import GraphedTrainStep
+from .parallel import ArenaReducer, GraphedTrainStep, dp_info
 
 
-def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runner=None):
+def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runner=None, reducer=None):
     if isinstance(net, torch.nn.Module):
         net.train()
     last = None
@@ -29,7 +29,10 @@ def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runn
         updater.zero_grad()
         l.mean().backward()
         if hasattr(net, "cfg"):
+            net.cfg.run_deferred()
             net.cfg.join_side()
+        if reducer is not None:
+            reducer.finish()                     # data parallel: the step waits for the averaged gradients
         updater.step()
         if hasattr(net, "cfg"):
             net.cfg.end_step()
@@ -39,9 +42,15 @@ def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runn
 
 def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=None, patience=None, saveat=None,
           start_from=None, verbose=False, device="cpu", scheduler=None, use_file=None, up_updater=False,
-          ret_lr=False, name=None, minimize=True, start_counting=0, use_graph=True, **kwargs):
+          ret_lr=False, name=None, minimize=True, start_counting=0, use_graph=True, save_last=None, **kwargs):
+    # data parallel (the reference's commented-out nn.DataParallel sits at train_funcs.py:72-74): every rank
+    # runs this loop on its shard of each global batch; gradients are averaged by the ArenaReducer, validation counters
+    # are summed over the ranks (mIoU_evaluator), so every rank takes the same early-stopping / scheduler decisions;
+    # only rank 0 writes messages and checkpoints
+    world, rank = dp_info(net)
+
     def say(msg):
-        if not verbose:
+        if not verbose or rank != 0:
             return
         if use_file:
             with open(use_file, "a") as f:
@@ -68,10 +77,16 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
         if patience and follow in save_dict:
             best_val = save_dict[follow]
     branchy = bool(kwargs.get("n_branches"))
-    runner = None
-    if use_graph and hasattr(net, "cfg") and net.cfg.arena is not None and hasattr(updater, "static_grads"):
-        runner = GraphedTrainStep(net, loss, updater)
+    runner = reducer = None
+    if world > 1 or (hasattr(net, "cfg") and net.cfg.dp_active()):
+        if not hasattr(net, "cfg") or net.cfg.arena is None:
+            raise RuntimeError("data-parallel training needs net.enable_grad_arena() (gradient buckets are arena slices)")
+        reducer = ArenaReducer(net, group=net.cfg.group)
+        use_graph = use_graph and net.cfg.collective is None        # the gloo test transport stages through the host
+    if hasattr(net, "cfg") and net.cfg.arena is not None and hasattr(updater, "static_grads"):
+        runner = GraphedTrainStep(net, loss, updater, reducer, use_graph=use_graph)
     epoch, last_lr = 0, 0
+    have_ckpt = os.path.exists(saveat)       # read once, before anybody writes: every rank must take the same branch below
     num_epochs = num_epochs or np.inf
     while epoch < num_epochs:
         epoch += 1
@@ -79,7 +94,9 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
         start = time.perf_counter()
         say(f"<< {name} progress update >> starting #{epoch} training epoch; lr = {cur_lr}, "
             f"no updates since {counter} epochs")
-        train_epoch(net, train_iter, loss, updater, device, runner)
+        if hasattr(getattr(train_iter, "sampler", None), "set_epoch"):
+            train_iter.sampler.set_epoch(epoch)
+        train_epoch(net, train_iter, loss, updater, device, runner, reducer)
         end = time.perf_counter() - start
         say(f"<< {name} progress update >> finished #{epoch} training epoch after {end // 60} mins and "
             f"{end - 60 * (end // 60):.2f} s")
@@ -111,16 +128,20 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
                 scheduler.step()
             if hasattr(updater, "sync_lr"):
                 updater.sync_lr()
+        if save_last and rank == 0:          # optional (not in the reference): the weights after the epoch just finished
+            torch.save({"model_state_dict": net.state_dict(), "epoch": epoch}, save_last)
         improved = (best_val > cur_val) if minimize else (best_val < cur_val)
         if patience and counter >= patience and epoch > start_counting:
             break
-        if improved or not os.path.exists(saveat):
+        if improved or not have_ckpt:
             save_dict = {"model_state_dict": deepcopy(net.state_dict()),
                          "opt_state_dict": deepcopy(updater.state_dict()), "epoch": epoch}
             for k in list(tracker.keys()):
                 if k.startswith("val_"):
                     save_dict[k] = tracker[k][-1]
-            torch.save(save_dict, saveat)
+            if rank == 0:
+                torch.save(save_dict, saveat)
+            have_ckpt = True
             if improved:
                 best_val = cur_val
                 counter = 0
@@ -133,4 +154,6 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
             last_lr = cur_lr
         else:
             counter += 1
+    if world > 1 and torch.distributed.is_initialized():
+        torch.distributed.barrier()          # rank 0's last checkpoint is on disk before any rank reloads it
     return tracker

@@ -237,9 +237,10 @@ int eeseg_broadcast_hw(const void* x, void* y, int ldy, int N, int HW, int C, fl
 /* Dropout(p) with a counter-based hash RNG: keep iff hash(seed', index) >= p with
  * seed' = seed + K*step_dev[0] (step_dev: optional device step counter, so a captured
  * HIP graph draws a fresh mask every replay); kept values are scaled by 1/(1-p).
- * Backward = the same call on dy. */
-int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step_dev, int dtype,
-                  void* stream);
+ * index = index_offset + element position: a data-parallel rank passes rank * n, so the ranks' masks are the slices of
+ * the mask ONE process would draw for the whole (rank-major) batch.  Backward = the same call on dy. */
+int eeseg_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const int64_t* step_dev,
+                  int64_t index_offset, int dtype, void* stream);
 int eeseg_cast(const void* x, int in_dtype, void* y, int out_dtype, int64_t n, void* stream);
 /* y[i] += x[i] (gradient accumulation at residual joins) */
 int eeseg_add_inplace(void* y, const void* x, int64_t n, int dtype, void* stream);
@@ -367,6 +368,31 @@ int eeseg_preprocess_image_u8(const uint8_t* src, int H, int W, int C, int Hr, i
                               uint8_t* tmp /* [H][Wr][C] */, float* out, void* stream);
 int eeseg_preprocess_label_u8(const uint8_t* src, int H, int W, const int32_t* yidx, const int32_t* xidx, int Hr, int Wr,
                               int crop_top, int crop_left, int Dh, int Dw, const int64_t* lut, int64_t* out, void* stream);
+
+/* ------------------------------------- data-parallel collectives -------
+ * The reference has no collective (nn.DataParallel is commented out, train_funcs.py:72-74): these are the exchange
+ * steps of the build's own data-parallel training path - gradient buckets, SyncBN (sum x, sum x^2) pairs, the global
+ * cross-entropy valid-pixel count, the exact-Lovasz all-gather, the per-exit mIoU counters (eval_mIoU.py:15-40 under DP).
+ * RCCL is called DIRECTLY and enqueues ONE kernel on the stream passed in - eagerly or inside a HIP-graph capture
+ * alike; there is no hidden stream, no completion event and no polling thread (DESIGN.md section 7 explains why
+ * torch.distributed's process group is not used for the data path).  State lives in the communicator handle only.
+ * librccl.so.1 is bound at run time (the copy the host process has already mapped, else /opt/rocm/lib).
+ *   rendezvous: rank 0 calls eeseg_comm_unique_id and hands the 128 bytes to every rank out of band (the Python host
+ *   uses torch.distributed's store / gloo); then EVERY rank calls eeseg_comm_create (collective, blocking) with its
+ *   device current (hipSetDevice).  Buffers are device memory of that device; `count` in elements, `bytes` in bytes.
+ *   In-place only.  All ranks must issue the same collectives in the same order per communicator. */
+enum { EESEG_COMM_F32 = 0, EESEG_COMM_BF16 = 1, EESEG_COMM_F64 = 2, EESEG_COMM_I32 = 3, EESEG_COMM_I64 = 4 };
+enum { EESEG_COMM_SUM = 0, EESEG_COMM_AVG = 1, EESEG_COMM_MAX = 2 };
+int eeseg_comm_available(int* rccl_version /* optional out */);       /* 0 when librccl could be bound */
+int eeseg_comm_unique_id(void* id128);
+int eeseg_comm_create(const void* id128, int world, int rank, void** comm_out);
+int eeseg_comm_destroy(void* comm);          /* the device must be idle w.r.t. this communicator (and graphs holding its kernels gone) */
+int eeseg_comm_info(void* comm, int* world, int* rank, int* device);
+int eeseg_comm_check(void* comm);            /* asynchronous RCCL error of the communicator, if any (does not touch the GPU) */
+int eeseg_comm_all_reduce(void* comm, void* buf, int64_t count, int dtype, int op, void* stream);
+int eeseg_comm_all_gather(void* comm, const void* send, void* recv /* [world][bytes_per_rank] */, int64_t bytes_per_rank,
+                          void* stream);
+int eeseg_comm_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
 
 #ifdef __cplusplus
 }

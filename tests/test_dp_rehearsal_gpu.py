@@ -1,7 +1,15 @@
-"""Single-GPU rehearsal of the multi-GPU code paths: a real `nccl` (RCCL) process group with ONE
-rank and EESEG_FORCE_ALLREDUCE=1, so SyncBN statistics, the global CE valid count and the gradient
-arena buckets all go through RCCL collectives - eagerly and inside the captured HIP graph.  With one
-rank every collective is the identity, so the result must equal the non-distributed run."""
+"""Single-GPU rehearsal of the multi-GPU code paths: real RCCL communicators (through libeeseg's C ABI,
+comm.DataParallelComm) with ONE rank and EESEG_FORCE_ALLREDUCE=1, so SyncBN statistics (forward on the compute
+stream, backward on the side lane beside the held-back weight gradient), the global CE valid count and the
+gradient arena buckets all go through RCCL kernels - eagerly and inside the captured HIP graph.  With one rank
+every collective is the identity, so the result must equal the non-distributed run.
+
+Round 2 ran this over torch.distributed's NCCL process group and one of three runs died in c10d's watchdog
+(hipErrorCapturedEvent).  Cause (scripts/captured_event_repro.hip): on HIP an event counts as
+captured as soon as the stream it was last recorded on is capturing; c10d records every Work's end event on its
+internal stream and the watchdog still held the warm-up steps' Works when that stream was forked into the
+capture.  The data path no longer creates c10d Works at all; the child below additionally keeps a live NCCL
+process group (with its watchdog) next to the capture to show the two no longer interact."""
 import os
 import socket
 
@@ -28,13 +36,14 @@ def _run(distributed, steps=4):
     from test_model_gpu import _inputs, _pair
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
     from ee_semantic_segmentation_amd.optim import SGD
-    from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, broadcast_parameters
+    from ee_semantic_segmentation_amd.parallel import ArenaReducer, GraphedTrainStep, init_data_parallel
     C, B, img = 21, 4, 97
     net, _ = _pair("deeplabv3_resnet50", 1, img, dropout=0.5)
     net.train()
     net.fused_outputs = True
-    net.cfg.sync_bn = distributed
-    broadcast_parameters(net)
+    comm = init_data_parallel(net, sync_bn=True) if distributed else None
+    assert (comm is not None) == distributed and net.cfg.sync_active() == distributed
+    assert not distributed or net.cfg.defer_wgrad          # the side-lane SyncBN backward is the default path
     net.enable_grad_arena()
     opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     red = ArenaReducer(net, bucket_bytes=32 << 20)
@@ -44,6 +53,12 @@ def _run(distributed, steps=4):
     Xd, yd = X.to(DEV), y.to(DEV)
     losses = [float(runner(Xd, yd).item()) for _ in range(steps)]
     assert runner.graph is not None, "graph capture fell back to eager"
+    if comm is not None:
+        comm.stat.check()
+        comm.grad.check()
+        runner.graph = None                 # captured RCCL kernels go before their communicators
+        del runner
+        comm.close()
     return np.array(losses)
 
 
@@ -52,9 +67,13 @@ def _child():
     import json
     base = _run(False)
     os.environ["EESEG_FORCE_ALLREDUCE"] = "1"
+    # an NCCL process group as the rendezvous group on purpose: its watchdog thread is alive during the capture
     dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}",
                             device_id=torch.device("cuda", 0))
-    print("RCCL_INIT_OK", flush=True)
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)                      # an eager c10d Work for the watchdog to hold
+    from ee_semantic_segmentation_amd.comm import rccl_version
+    print("RCCL_INIT_OK", rccl_version(), flush=True)
     try:
         got = _run(True)
     finally:

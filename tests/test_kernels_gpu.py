@@ -247,6 +247,10 @@ def test_gap_broadcast_dropout_cast_add(dtype):
     assert torch.equal(d1, d2) and not torch.equal(d1, d3)
     keep = (d1 != 0).float().mean().item()
     assert abs(keep - 0.5) < 0.01 and set(d1.float().unique().tolist()) == {0.0, 2.0}
+    # data parallel: rank r passes index_offset = r * n and draws the r-th slice of the whole batch's mask
+    half = x[:2].contiguous()
+    lo, hi = K.dropout(half, 0.5, 123), K.dropout(half, 0.5, 123, index_offset=half.numel())
+    assert torch.equal(torch.cat([lo, hi]), d1)
     # cast / add / colsum
     f = torch.randn(1000, 64, device=DEV)
     close(K.cast(f, torch.bfloat16), f.bfloat16(), 1e-6, "cast")
