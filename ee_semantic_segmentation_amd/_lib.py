@@ -91,8 +91,8 @@ SIGNATURES = {
     "eeseg_preprocess_image_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp,
                                        _vp, _vp, _vp]),
     "eeseg_preprocess_label_u8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
     "eeseg_argmax_pair_hist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "eeseg_entropy_gate_active": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eeseg_argmax_exit": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -102,7 +102,7 @@ SIGNATURES = {
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),
     "eeseg_lovasz_workspace": (_i64, [_i64, _i]),
-    "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _vp, _i64, _vp]),
+    "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _u64, _i, _vp, _i64, _vp]),
     "eeseg_sgd_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "eeseg_comm_available": (_i, [C.POINTER(_i)]),
     "eeseg_comm_unique_id": (_i, [_vp]),

@@ -11,8 +11,8 @@ Notes on LovaszSoftmax:
 Faithful quirks: the exits' RAW LOGITS are fed to the Lovasz extension (SURVEY F6 /
 B-4: the reference never applies a softmax), per_image=False ranks all pixels of the
 batch jointly, the per-exit losses are summed (or linspace-weighted with ``prev_out``).
-Only classes='present' and per_image=False (what main_bradeepv3.py:121 uses) run on
-the GPU path.
+classes = 'present' (what main_bradeepv3.py:121 uses), 'all' or a list, per_image False / True: all on
+the GPU path (lovaszsoftmax.py:154-169,185-188).
 """
 import torch
 from torch import nn
@@ -23,12 +23,12 @@ from .from_deepv3_new import ExitLogits
 
 class _LovaszFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scores, target, ignore):
+    def forward(ctx, scores, target, ignore, classes):
         scores = scores.contiguous()
         need = scores.requires_grad or torch.is_grad_enabled()
         # gradient is produced in the same pass as the loss (it is the sorted Jaccard
         # increment scattered back), so compute it now with unit scale
-        loss, ds = K.lovasz(scores.detach(), target, ignore, want_grad=need)
+        loss, ds = K.lovasz(scores.detach(), target, ignore, want_grad=need, classes=classes)
         ctx.save_for_backward(ds) if ds is not None else None
         ctx.has = ds is not None
         return loss[0]
@@ -36,19 +36,25 @@ class _LovaszFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if not ctx.has:
-            return None, None, None
+            return None, None, None, None
         (ds,) = ctx.saved_tensors
-        return ds * g, None, None
+        return ds * g, None, None, None
 
 
 def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
-    """lovaszsoftmax.py:154-169 restricted to the configuration the reference trains with."""
-    if classes != "present" or per_image:
-        raise NotImplementedError("the HIP Lovasz path implements classes='present', per_image=False")
+    """lovaszsoftmax.py:154-169.  classes: 'present', 'all' or a list of class indices (:185-188).  per_image=True
+    (:165-166): every image is ranked alone and the per-image losses are averaged - one segmented sort per image (the
+    sort segments are (image, class) pairs instead of classes)."""
     if labels.dim() > 3:
         labels = labels.squeeze(1)
     labels = labels.contiguous().long()
-    return _LovaszFn.apply(probas.float(), labels, ignore)
+    probas = probas.float()
+    if not isinstance(classes, str):
+        classes = tuple(int(c) for c in classes)
+    if not per_image:
+        return _LovaszFn.apply(probas, labels, ignore, classes)
+    per = [_LovaszFn.apply(probas[n:n + 1], labels[n:n + 1], ignore, classes) for n in range(probas.shape[0])]
+    return torch.stack(per).sum() / len(per)            # lovaszsoftmax.py:233-251 `mean`
 
 
 class LovaszSoftmax(nn.Module):
@@ -80,7 +86,9 @@ class LovaszSoftmax(nn.Module):
     def forward(self, y_pred, targets):
         losses = []
         comm = getattr(y_pred, "cfg", None) or self.comm
-        gather = comm is not None and comm.dp_active() and not self.per_shard
+        # per_image=True ranks every image alone: the mean over a rank's images, averaged over equal shards by the
+        # data-parallel reducer, IS the whole batch's loss - nothing to gather
+        gather = comm is not None and comm.dp_active() and not self.per_shard and not self.per_image
         if gather:
             t = targets.squeeze(1) if targets.dim() > 3 else targets
             targets = comm.all_gather(t.contiguous()).flatten(0, 1)
@@ -110,11 +118,11 @@ class _ClassSums(torch.autograd.Function):
     """(S, I, T, void, F) of one exit from its low-res logits; differentiable in S, I, F."""
 
     @staticmethod
-    def forward(ctx, lr, target, C, H, W, gamma, alpha):
+    def forward(ctx, lr, target, C, H, W, gamma, alpha, alpha_batch_sum=False):
         lr = lr.contiguous()
-        sums, extra = K.class_sums_fwd(lr.detach(), C, target, H, W, gamma, alpha)
+        sums, extra = K.class_sums_fwd(lr.detach(), C, target, H, W, gamma, alpha, alpha_batch_sum)
         ctx.save_for_backward(lr, target, alpha if alpha is not None else torch.empty(0, device=lr.device))
-        ctx.meta = (C, H, W, gamma, alpha is not None)
+        ctx.meta = (C, H, W, gamma, alpha is not None, alpha_batch_sum)
         S, I, T = sums[:, 0, :C].float(), sums[:, 1, :C].float(), sums[:, 2, :C].float()
         ctx.mark_non_differentiable(T)
         void, F = extra[:, 0].float(), extra[:, 1].float()
@@ -124,7 +132,7 @@ class _ClassSums(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gS, gI, _gT, _gV, gF):
         lr, target, alpha = ctx.saved_tensors
-        C, H, W, gamma, has_alpha = ctx.meta
+        C, H, W, gamma, has_alpha, batch_sum = ctx.meta
         N = lr.shape[0]
 
         def pad(g):
@@ -141,13 +149,15 @@ class _ClassSums(torch.autograd.Function):
         dlr = torch.zeros_like(lr)
         if gf is None or N == 1 or bool((gf == gf[0]).all()):
             K.class_sums_bwd(lr, C, target, H, W, pad(gS), pad(gI), None if gf is None else gf[:1].contiguous(), dlr, gamma,
-                             alpha if has_alpha else None)
+                             alpha if has_alpha else None, batch_sum)
+        elif batch_sum:
+            raise NotImplementedError("faithful FocalLoss alpha couples the images of a batch: reduce with 'mean' / 'sum'")
         else:                       # image-dependent focal weights: one launch per image
             K.class_sums_bwd(lr, C, target, H, W, pad(gS), pad(gI), None, dlr, gamma, alpha if has_alpha else None)
             for n in range(N):
                 K.class_sums_bwd(lr[n:n + 1], C, target[n:n + 1], H, W, None, None, gf[n:n + 1].contiguous(), dlr[n:n + 1],
                                  gamma, alpha if has_alpha else None)
-        return dlr, None, None, None, None, None, None
+        return dlr, None, None, None, None, None, None, None
 
 
 def _exit_lowres(y_pred, i):
@@ -183,9 +193,9 @@ class BrSegLoss(nn.Module):
     def update_n(self, n):
         self.n = n + 1
 
-    def _sums(self, y_pred, i, targets, gamma=-1.0, alpha=None, allow_void=False):
+    def _sums(self, y_pred, i, targets, gamma=-1.0, alpha=None, allow_void=False, alpha_batch_sum=False):
         lr, C, (H, W) = _exit_lowres(y_pred, i)
-        S, I, T, void, F = _ClassSums.apply(lr, targets, C, H, W, gamma, alpha)
+        S, I, T, void, F = _ClassSums.apply(lr, targets, C, H, W, gamma, alpha, alpha_batch_sum)
         if not allow_void and float(void.sum()) > 0:
             # the reference one-hot encodes / gathers with num_classes = C and fails the same way on a void label
             raise RuntimeError("Class values must be smaller than num_classes.")
@@ -265,18 +275,31 @@ class FocalTverskyLoss(TverskyLoss):
 
 class FocalLoss(BrSegLoss):
     """:113-131.  The reference returns the per-pixel map [N,H,W] and reduces it afterwards; the fused kernel
-    reduces on the fly, so only reduction 'mean' / 'sum' are available (the map is never materialised)."""
+    reduces on the fly, so only reduction 'mean' / 'sum' are available (the map is never materialised).
 
-    def __init__(self, alpha=None, gamma=2, smooth=1e-6, reduction="mean", n_branches=1, weights=None):
+    ``alpha``: the reference multiplies the [B,H,W] loss map by ``alpha[targets]`` of shape [B,1,H,W], which broadcasts
+    to [B,B,H,W] - every image's loss is weighted by every image's alpha map (:126-129).  ``faithful_alpha=True``
+    (default: what a drop-in must return, golden-pinned for every batch size) reproduces exactly that: summed over the
+    extra axis it is a per-pixel weight sum_i alpha[t_i(h,w)], evaluated inside the fused kernels
+    (eeseg_class_sums_* alpha_batch_sum).  ``faithful_alpha=False`` weights each pixel by the alpha of its own label -
+    the evident intent; the two coincide for batch size 1."""
+
+    def __init__(self, alpha=None, gamma=2, smooth=1e-6, reduction="mean", n_branches=1, weights=None,
+                 faithful_alpha=True):
         super().__init__(smooth, reduction, n_branches, weights)
         if reduction not in ("mean", "sum"):
             raise NotImplementedError("fused FocalLoss reduces on the fly: reduction must be 'mean' or 'sum'")
         self.alpha = None if alpha is None else torch.as_tensor(alpha, dtype=torch.float32)
         self.gamma = gamma
+        self.faithful_alpha = faithful_alpha
 
     def _compute_loss(self, y_pred, i, targets):
         lr = _exit_lowres(y_pred, i)[0]
         alpha = None if self.alpha is None else self.alpha.to(lr.device).contiguous()
-        _, _, _, F, _, hw = self._sums(y_pred, i, targets, gamma=float(self.gamma), alpha=alpha)
+        batch_sum = alpha is not None and self.faithful_alpha and lr.shape[0] > 1
+        _, _, _, F, _, hw = self._sums(y_pred, i, targets, gamma=float(self.gamma), alpha=alpha, alpha_batch_sum=batch_sum)
         # [N] per-image sums; 'mean' over [N,H,W] = sum / (N*H*W): scale so that BrSegLoss.forward's mean over dim 1 fits
-        return F / hw if self.reduction == "mean" else F
+        # (the faithful alpha form averages over [N,N,H,W]: one more factor N)
+        if self.reduction == "mean":
+            return F / (hw * lr.shape[0]) if batch_sum else F / hw
+        return F

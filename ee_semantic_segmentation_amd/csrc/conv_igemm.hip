@@ -2170,7 +2170,12 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }
-        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 && (g_conv_pw_all || a->Cout >= 2 * a->Cin || a->residual)) {
+        // small M (the 4-images-per-GPU shard of an 8-GPU run: 67 tiles of 256 pixels): on the 256-tile kernel EVERY tile of a
+        // contracting layer would be a K-split + fix-up launch; the 128x256 kernel covers the same layer in one launch of
+        // whole tiles (measured at 4 x 65 x 65, R101 step: 24.32 -> 23.74 ms; neutral at 8 images)
+        const bool small_m = ((M + BIGT - 1) / BIGT) * (a->Cout / BIGT) <= g_conv_big_cus / 2;
+        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 &&
+            (g_conv_pw_all || a->Cout >= 2 * a->Cin || a->residual || small_m)) {
             p.n_tiles = a->Cout / PW_BN;
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);

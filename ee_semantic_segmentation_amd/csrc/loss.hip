@@ -441,10 +441,23 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_span_kernel(const float* 
 // logits); Focal (:113-131) is a per-pixel sum F = sum -alpha_t (1 - p_t)^gamma log p_t.  One pass computes all of
 // them from the low-res logits (same span scheme as the CE kernels).  grid.y = image.
 // sums [N][3][CMAX] double (+=), extra [N][2] double (+=): [0] pixels with a label outside [0,C), [1] F.
+// FocalLoss(alpha=...) as the reference COMPUTES it (branchy_seg_losses.py:126-129): the [B,H,W] loss map times
+// alpha[targets] of shape [B,1,H,W] broadcasts to [B,B,H,W] - every image's loss at a pixel is weighted by the alphas of
+// ALL images' labels at that pixel.  Summed over the extra axis that is the per-pixel weight sum_i alpha[t[i][y][x]].
+__device__ __forceinline__ float focal_alpha_batch_sum(const float* __restrict__ alpha, const int64_t* __restrict__ target,
+                                                       int N, int C, int H, int W, int y, int x) {
+    float a = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const long long t = target[((long long)i * H + y) * W + x];
+        if (t >= 0 && t < C) a += alpha[(int)t];
+    }
+    return a;
+}
+
 __global__ __launch_bounds__(256) void class_sums_fwd_kernel(const float* __restrict__ lr, int ldc,
                                                              const int64_t* __restrict__ target, int C, int h, int w,
                                                              int H, int W, float gamma, const float* __restrict__ alpha,
-                                                             double* sums, double* extra) {
+                                                             int alpha_batch_sum, double* sums, double* extra) {
     __shared__ float red[8][4][32];
     __shared__ float red2[8][2];
     const int n = blockIdx.y;
@@ -491,7 +504,8 @@ __global__ __launch_bounds__(256) void class_sums_fwd_kernel(const float* __rest
                     const float zt = __shfl(z, (int)tg, 32);
                     const float logq = zt - (m + __logf(ssum));
                     const float q = __expf(logq);
-                    const float a = alpha ? alpha[(int)tg] : 1.f;
+                    const float a = alpha ? (alpha_batch_sum ? focal_alpha_batch_sum(alpha, target, gridDim.y, C, H, W, y, x)
+                                                             : alpha[(int)tg]) : 1.f;
                     aF += -a * __powf(fmaxf(1.f - q, 0.f), gamma) * logq;
                 }
             } else {
@@ -524,7 +538,8 @@ __global__ __launch_bounds__(256) void class_sums_bwd_kernel(const float* __rest
                                                              const int64_t* __restrict__ target, int C, int h, int w,
                                                              int H, int W, const float* __restrict__ gS,
                                                              const float* __restrict__ gI, const float* __restrict__ gF,
-                                                             float gamma, const float* __restrict__ alpha, float* dlr) {
+                                                             float gamma, const float* __restrict__ alpha,
+                                                             int alpha_batch_sum, float* dlr) {
     const int n = blockIdx.y;
     const int lane32 = threadIdx.x & 31;
     const int half = threadIdx.x >> 5;
@@ -571,7 +586,8 @@ __global__ __launch_bounds__(256) void class_sums_bwd_kernel(const float* __rest
                 const float logq = zt - (m + __logf(s));
                 const float q = __expf(logq);
                 const float omq = fmaxf(1.f - q, 0.f);
-                const float a = alpha ? alpha[(int)tg] : 1.f;
+                const float a = alpha ? (alpha_batch_sum ? focal_alpha_batch_sum(alpha, target, gridDim.y, C, H, W, y, x)
+                                                         : alpha[(int)tg]) : 1.f;
                 const float k = gamma == 0.f ? -1.f : gamma * __powf(omq, gamma - 1.f) * q * logq - __powf(omq, gamma);
                 r += gf * a * k * ((mine ? 1.f : 0.f) - pr);
             }
@@ -875,26 +891,27 @@ extern "C" int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int
 }
 
 extern "C" int eeseg_class_sums_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H,
-                                    int W, float gamma, const float* alpha, double* sums, double* extra, void* stream) {
+                                    int W, float gamma, const float* alpha, int alpha_batch_sum, double* sums, double* extra,
+                                    void* stream) {
     CHECK_LR("class_sums_fwd");
     EESEG_CHECK(target && sums && extra, EESEG_ERR_ARG, "class_sums_fwd: null pointer");
     long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(class_sums_fwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc,
-                       target, C, h, w, H, W, gamma, alpha, sums, extra);
+                       target, C, h, w, H, W, gamma, alpha, alpha_batch_sum, sums, extra);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }
 
 extern "C" int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H,
                                     int W, const float* gS, const float* gI, const float* gF, float gamma,
-                                    const float* alpha, float* dlogits_lr, void* stream) {
+                                    const float* alpha, int alpha_batch_sum, float* dlogits_lr, void* stream) {
     CHECK_LR("class_sums_bwd");
     EESEG_CHECK(target && dlogits_lr && (gS || gI || gF), EESEG_ERR_ARG, "class_sums_bwd: null pointer");
     long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(class_sums_bwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc,
-                       target, C, h, w, H, W, gS, gI, gF, gamma, alpha, dlogits_lr);
+                       target, C, h, w, H, W, gS, gI, gF, gamma, alpha, alpha_batch_sum, dlogits_lr);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -1,5 +1,6 @@
 // Multi-class Lovasz loss on RAW scores for one exit (branchy_seg_losses.py:154 ->
-// lovaszsoftmax.py:172-200, per_image=False, classes='present'), fully on device:
+// lovaszsoftmax.py:172-200; classes = 'present' | 'all' | list as a class mask + present_only flag; per_image=True is
+// the host calling this once per image), fully on device:
 //   1. prep : key[c][p] = |1[y_p=c] - s_pc| (valid pixels) or -1 (void: sorts last),
 //             val = pixel index | foreground bit 30 | sign bit 31;  class pixel counts G[c], #valid pixels
 //   2. sort : hand-written segmented LSD radix sort (4 passes of 8 bits, descending, one
@@ -233,10 +234,16 @@ __global__ __launch_bounds__(256) void lv_block_counts(const unsigned* __restric
     if (threadIdx.x == 0) bsum[(size_t)c * nblk + b] = s;
 }
 
-// number of present classes (the block counts are scanned by rs_scan, one block per class)
-__global__ void lv_count_present(int C, const int* G, LvHeader* hdr) {
+// class c takes part in the mean: selected by the caller's mask and, for classes='present', present in the labels
+// (lovaszsoftmax.py:185-188: 'all' and explicit lists keep absent classes - an absent class contributes max |score|)
+__device__ __forceinline__ bool lv_counted(int c, int g, unsigned long long class_mask, int present_only) {
+    return ((class_mask >> c) & 1ull) && (!present_only || g > 0);
+}
+
+// number of classes in the mean (the block counts are scanned by rs_scan, one block per class)
+__global__ void lv_count_present(int C, const int* G, LvHeader* hdr, unsigned long long class_mask, int present_only) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C && G[c] > 0) atomicAdd(&hdr->n_present, 1);
+    if (c < C && lv_counted(c, G[c], class_mask, present_only)) atomicAdd(&hdr->n_present, 1);
 }
 
 __device__ __forceinline__ float jaccard(float G, float F, float kp1) {   // 1 - (G-F)/(G + k+1 - F)
@@ -247,13 +254,13 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
                                                 const int64_t* __restrict__ target, long long P, int nblk, int C,
                                                 int HW, const int* __restrict__ G, const int* __restrict__ bsum,
                                                 const LvHeader* hdr, double* class_loss, float* dscores, float gscale,
-                                                const float* gscale_dev) {
+                                                const float* gscale_dev, unsigned long long class_mask, int present_only) {
     __shared__ int swave[4];
     __shared__ double sloss[4];
     const int c = blockIdx.y, b = blockIdx.x;
     const int nv = hdr->n_valid;
     const int g = G[c];
-    if (g == 0 || (long long)b * SB >= nv) return;       // class absent / block past the valid range
+    if (!lv_counted(c, g, class_mask, present_only) || (long long)b * SB >= nv) return;   // class not in the mean / block past the valid range
     const float Gf = (float)g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // each thread owns 8 consecutive elements
@@ -313,13 +320,14 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
     if (threadIdx.x == 0) atomicAdd(&class_loss[c], sloss[0] + sloss[1] + sloss[2] + sloss[3]);
 }
 
-__global__ void lv_loss(const double* class_loss, const int* G, int C, const LvHeader* hdr, float* loss_out) {
+__global__ void lv_loss(const double* class_loss, const int* G, int C, const LvHeader* hdr, float* loss_out,
+                        unsigned long long class_mask, int present_only) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double s = 0.0;
         int n = 0;
         for (int c = 0; c < C; ++c)
-            if (G[c] > 0) { s += class_loss[c]; ++n; }
-        loss_out[0] = n ? (float)(s / n) : 0.f;           // only void pixels: 0 (lovaszsoftmax.py:181-183)
+            if (lv_counted(c, G[c], class_mask, present_only)) { s += class_loss[c]; ++n; }
+        loss_out[0] = (n && hdr->n_valid > 0) ? (float)(s / n) : 0.f;   // only void pixels: 0 (lovaszsoftmax.py:181-183)
     }
 }
 
@@ -355,9 +363,10 @@ extern "C" int64_t eeseg_lovasz_workspace(int64_t P, int C) {
 }
 
 extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
-                            float* loss_out, float* dscores, float gscale, const float* gscale_dev, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
+                            float* loss_out, float* dscores, float gscale, const float* gscale_dev, uint64_t class_mask,
+                            int present_only, void* workspace, int64_t workspace_bytes, void* stream) {
     EESEG_CHECK(scores && target && loss_out && workspace, EESEG_ERR_ARG, "lovasz: null pointer");
+    EESEG_CHECK(present_only == 0 || present_only == 1, EESEG_ERR_ARG, "lovasz: present_only must be 0 or 1");
     EESEG_CHECK(N > 0 && C > 0 && C <= 64 && HW > 0, EESEG_ERR_ARG, "lovasz: bad shape (C <= 64)");
     const long long P = (long long)N * HW;
     EESEG_CHECK(P * C < (1ll << 31), EESEG_ERR_TOO_LARGE, "lovasz: N*HW*C must be < 2^31");
@@ -404,10 +413,11 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     vals_out = va;
     hipLaunchKernelGGL(lv_block_counts, dim3(nblk, C), dim3(256), 0, st, vals_out, target, P, nblk, hdr, bsum);
     hipLaunchKernelGGL(rs_scan, dim3(C), dim3(1024), 0, st, (unsigned*)bsum, nblk, (unsigned*)nullptr);
-    hipLaunchKernelGGL(lv_count_present, dim3(1), dim3(64), 0, st, C, G, hdr);
+    const unsigned long long cm = (unsigned long long)class_mask;
+    hipLaunchKernelGGL(lv_count_present, dim3(1), dim3(64), 0, st, C, G, hdr, cm, present_only);
     hipLaunchKernelGGL(lv_final, dim3(nblk, C), dim3(256), 0, st, keys_out, vals_out, target, P, nblk, C, HW, G, bsum, hdr,
-                       closs, dscores, gscale, gscale_dev);
-    hipLaunchKernelGGL(lv_loss, dim3(1), dim3(64), 0, st, closs, G, C, hdr, loss_out);
+                       closs, dscores, gscale, gscale_dev, cm, present_only);
+    hipLaunchKernelGGL(lv_loss, dim3(1), dim3(64), 0, st, closs, G, C, hdr, loss_out, cm, present_only);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

