@@ -85,6 +85,23 @@ def _rccl_version():
     return rccl_version()
 
 
+def _staged_transport(world):
+    """REHEARSAL ONLY (--dp-transport gloo): the collectives of an N-rank step staged through host memory over gloo, so the
+    multi-process plumbing of this file (rendezvous, shards, barriers, rank-0 line, teardown) can be run with N ranks on
+    ONE GPU, where ranks cannot share an RCCL communicator.  Never a measurement: the step cannot be graph-captured."""
+    def reduce_(t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+
+    def gather_(t, group):
+        h = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.stack(parts).to(t.device)
+    return reduce_, gather_
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -107,7 +124,7 @@ class Run:
         # EESEG_FORCE_ALLREDUCE=1 (with RANK/WORLD_SIZE=1 set): a 1-rank communicator still issues every collective -
         # rehearses the N > 1 graph (SyncBN all-reduces, CE count, arena buckets) on one GPU
         net.cfg.overlap_wgrad = args.overlap_wgrad
-        init_data_parallel(net, sync_bn=sync_bn)
+        init_data_parallel(net, sync_bn=sync_bn, transport=_staged_transport(world) if args.dp_transport == "gloo" else None)
         self.E = net.n_branches + 1
         if loss == "lovasz":
             from ee_semantic_segmentation_amd import branchy_seg_losses as BSL
@@ -124,7 +141,8 @@ class Run:
         net.train()
         # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
         # HIP graph and every later call is a replay
-        self.runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2, use_graph=not args.no_graph)
+        self.runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2,
+                                       use_graph=not args.no_graph and net.cfg.collective is None)
         self.net = net
 
     def step(self):
@@ -263,6 +281,9 @@ def main():
                     help="A/B switch: eeseg_set_option(KEY, VALUE) (include/eeseg.h EESEG_OPT_*); repeatable")
     ap.add_argument("--ew-grid-cap", type=int, default=None)
     ap.add_argument("--wgrad-blocks", type=int, default=None)
+    ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "gloo"],
+                    help="rccl (default): RCCL through libeeseg.  gloo: REHEARSAL of the N-rank plumbing on one GPU - "
+                         "collectives staged through the host, no graph capture; the line is marked, never a measurement")
     ap.add_argument("--overlap-wgrad", type=int, default=0, nargs="?", const=1,
                     help="weight-gradient kernels on a side stream: 1 = beside the data-gradient, 2 = after it, beside the "
                          "BatchNorm backward of the layer below (per-kernel timings then overlap)")
@@ -277,6 +298,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("EESEG_REHEARSAL_ONE_GPU") == "1":          # N ranks on the only GPU of a test box (--dp-transport gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
@@ -342,7 +365,8 @@ def main():
                            "step_ms_hip_events": {"median": run.step_ms_median, "min": run.step_ms_min,
                                                   "max": run.step_ms_max, "rank": 0},
                            "collectives": ("RCCL %d via libeeseg, 2 communicators, package-owned lanes" % _rccl_version())
-                           if run.net.cfg.comm is not None else None,
+                           if run.net.cfg.comm is not None else
+                           ("REHEARSAL: staged through the host over gloo - not a measurement" if run.net.cfg.collective else None),
                            "flop_per_image": flop_img, "loss_last_step": loss_val,
                            "splits": list(run.net.split_names)},
                 "roofline": roof}

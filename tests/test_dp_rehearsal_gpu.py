@@ -122,3 +122,33 @@ def test_rccl_collectives_in_graph_match_local_run():
 if __name__ == "__main__" and "--child" in __import__("sys").argv:
     __import__("sys").path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _child()
+
+
+def test_bench_two_ranks_plumbing_on_one_gpu():
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`), with N = 2 on
+    this box's ONE GPU: two ranks cannot share an RCCL communicator there, so the collectives are staged through the
+    host over gloo (`--dp-transport gloo`, marked as a rehearsal in the line).  Everything else is the real N-rank
+    path: gloo rendezvous, per-rank shards of the global batch (strong scaling), SyncBN, arena buckets, barriers,
+    MAX-over-ranks timing, ONE JSON line from rank 0, collective teardown."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EESEG_REHEARSAL_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "EESEG_FORCE_ALLREDUCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dp-transport", "gloo", "--arch", "resnet50", "--branches", "1", "--img", "129", "--global-batch", "4",
+           "--no-kernel-events", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    cfg = d["config"]
+    assert cfg["global_batch"] == 4 and cfg["batch_per_gpu"] == 2 and cfg["parallelism"] == "dp2" and cfg["sync_bn"] is True
+    assert "REHEARSAL" in cfg["collectives"] and cfg["hip_graph"] is False
+    assert np.isfinite(cfg["loss_last_step"])

@@ -1111,3 +1111,4 @@ def test_conv_256_tile_mfma_16x16x32(case):
             close(sums[1].cpu(), (flat * flat).sum(1).float(), 2e-3, f"mfma16={m16} sum of squares")
     close(outs[1][0], outs[0][0], 8e-3, "16x16x32 vs 32x32x16")
     assert torch.equal(outs[2][0], outs[1][0]), "software-pipelined loop: same MFMAs in the same order, same bits"
+
