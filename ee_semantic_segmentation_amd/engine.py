@@ -354,6 +354,8 @@ class AllGatherRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, cfg):
+        # equal shards on every rank (parallel.ShardSampler drops the ragged last batch): the collective needs equal
+        # sizes, and backward's "x world" is exact only under the AVERAGING gradient reducer
         ctx.cfg, ctx.n = cfg, t.shape[0]
         return cfg.all_gather(t.contiguous()).flatten(0, 1)
 
@@ -426,21 +428,71 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
     return y, (x, c, None, mi, count, relu, ss)
 
 
-def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False, dx_add=None,
-                dc_out=None):
-    """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
-    parameter gradients are None in arena mode (written in place).  dx_add=(t, mask): the data-gradient adds
-    t * mask (bit mask) in its epilogue - the masked block gradient of a bottleneck, never materialised."""
+def conv_bn_fwd_group(cfg, items, frozen=False):
+    """conv_bn_fwd for several INDEPENDENT layers: items = [(x, conv, bn, relu, out)] -> [(y, state)].  Under SyncBN the
+    layers' (sum x, sum x^2) pairs travel in ONE all-reduce instead of one each ("coalesce where the dependency
+    graph allows - the 5 ASPP branches share one call"): all convs first, their partial sums reduced into slices of one
+    flat buffer, one collective, then finalize + apply per layer.  Without SyncBN it is the plain loop."""
+    if frozen or not cfg.sync_active() or len(items) < 2:
+        return [conv_bn_fwd(cfg, x, conv, bn, relu, out=out, frozen=frozen) for x, conv, bn, relu, out in items]
+    widths = [conv.weight.shape[0] for _, conv, _, _, _ in items]
+    flat = torch.empty(2 * sum(widths), dtype=torch.float32, device=items[0][0].device)
+    pend, off = [], 0
+    for (x, conv, bn, relu, out), cw in zip(items, widths):
+        wf, _ = packed(conv, x.dtype)
+        s, p, d = _geom(conv)
+        c, part = K.conv_fwd(x, wf, s, p, d, want_stats=True)
+        sums = flat[off:off + 2 * cw].view(2, cw)
+        K.reduce_partials(part, out=sums)
+        pend.append((c, sums, c.numel() // c.shape[-1]))
+        off += 2 * cw
+    cfg.all_reduce(flat)
+    res = []
+    for (x, conv, bn, relu, out), (c, sums, count) in zip(items, pend):
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        mi, ss = K.bn_finalize(sums, count * cfg.world(), bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+        bn._pending_batches += 1
+        y = K.bn_apply(c, ss, relu=relu, out=out)
+        res.append((y, (x, c, None, mi, count * cfg.world(), relu, ss)))
+    return res
+
+
+def bn_bwd_local_sums(cfg, st, dy, bn):
+    """First half of conv_bn_bwd for a train-mode layer under SyncBN: this rank's (sum g, sum g x_hat) - written into the
+    gradient arena as (dbeta, dgamma) like conv_bn_bwd does - returned as a fresh [2,C] tensor for the collective."""
     x, c, y, mi, count, relu, ss = st[:7]
-    frozen = len(st) > 7 and st[7]
     pair = cfg.gview(bn)
     if pair is not None and cfg.accumulate:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
         pair.add_(sums)
     else:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
+    return sums
+
+
+def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=False, x_is_col=False, dx_add=None,
+                dc_out=None, synced_sums=None, local_sums=None):
+    """Backward of conv_bn_fwd.  Returns (dx, dres, dW(param layout view), dgamma, dbeta); the three
+    parameter gradients are None in arena mode (written in place).  dx_add=(t, mask): the data-gradient adds
+    t * mask (bit mask) in its epilogue - the masked block gradient of a bottleneck, never materialised."""
+    x, c, y, mi, count, relu, ss = st[:7]
+    frozen = len(st) > 7 and st[7]
+    pair = cfg.gview(bn)
+    if synced_sums is not None:
+        # the caller reduced this layer's sums together with its siblings' (head_bwd: one collective for the ASPP branches):
+        # `local_sums` = this rank's (already in the arena), `synced_sums` = the group's
+        sums = local_sums
+    elif pair is not None and cfg.accumulate:
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
+        pair.add_(sums)
+    else:
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
-    if frozen:
+    if synced_sums is not None:
+        if pair is None:
+            dbeta, dgamma = dbeta.clone(), dgamma.clone()
+        sums = synced_sums
+    elif frozen:
         # statistics are constants: dc = g * gamma * invstd, i.e. the train-mode formula without its two mean terms
         sums = torch.zeros_like(sums)
     elif cfg.sync_active():
@@ -664,21 +716,20 @@ def head_fwd(cfg, x, head, train, frozen=False):
     mid = aspp.project[0].weight.shape[0]
     cat = torch.empty((N, h, w, nb * mid), dtype=x.dtype, device=x.device)
     states = []
-    for i in range(nb - 1):
-        seq = aspp.convs[i]
-        sl = cat[..., i * mid:(i + 1) * mid]
-        if keep:
-            _, st = conv_bn_fwd(cfg, x, seq[0], seq[1], True, out=sl, frozen=frozen)
-            states.append(st)
-        else:
-            conv_bn_eval(cfg, x, seq[0], seq[1], True, out=sl)
     # image pooling branch: GAP -> 1x1 conv -> BN -> ReLU -> broadcast
     pool = aspp.convs[nb - 1]
     g = K.sum_hw(x, 1.0 / (h * w)).view(N, 1, 1, cin)
     if keep:
-        pv, stp = conv_bn_fwd(cfg, g, pool[1], pool[2], True, frozen=frozen)
-        states.append(stp)
+        # the five branches are independent: under SyncBN their statistics share ONE collective (conv_bn_fwd_group)
+        items = [(x, aspp.convs[i][0], aspp.convs[i][1], True, cat[..., i * mid:(i + 1) * mid]) for i in range(nb - 1)]
+        items.append((g, pool[1], pool[2], True, None))
+        res = conv_bn_fwd_group(cfg, items, frozen=frozen)
+        states = [st for _, st in res]
+        pv = res[-1][0]
     else:
+        for i in range(nb - 1):
+            seq = aspp.convs[i]
+            conv_bn_eval(cfg, x, seq[0], seq[1], True, out=cat[..., i * mid:(i + 1) * mid])
         pv = conv_bn_eval(cfg, g, pool[1], pool[2], True)
     K.broadcast_hw(pv.view(N, mid), cat[..., (nb - 1) * mid:])
     proj = aspp.project
@@ -751,6 +802,21 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
     ntaps = sum(cv.kernel_size[0] * cv.kernel_size[1] for cv in convs)
     merge = (cfg.merge_aspp_dgrad and dcat.is_cuda and all(cv.stride[0] == 1 for cv in convs) and
              K.multi_dgrad_ok(dcat.dtype, cin, mid, ntaps))
+    # SyncBN: the five branches' backward sums share ONE collective (as their forward statistics do): local sums of every
+    # branch first, one all-reduce of the concatenation, then each branch continues with its slice
+    pool = aspp.convs[nb - 1]
+    dpv = K.sum_hw(dcat[..., (nb - 1) * mid:]).view(N, 1, 1, mid)
+    synced = [None] * nb
+    local = [None] * nb
+    if cfg.sync_active() and not (len(states[0]) > 7 and states[0][7]):
+        bns = [aspp.convs[i][1] for i in range(nb - 1)] + [pool[2]]
+        dys = [dcat[..., i * mid:(i + 1) * mid] for i in range(nb - 1)] + [dpv]
+        flat = torch.empty((nb, 2, mid), dtype=torch.float32, device=dcat.device)
+        for i in range(nb):
+            local[i] = bn_bwd_local_sums(cfg, states[i], dys[i], bns[i])
+            flat[i].copy_(local[i])
+        cfg.all_reduce(flat)
+        synced = [flat[i] for i in range(nb)]
     if merge:
         # ONE data-gradient launch for the 1x1 + atrous branches (generalised taps): dx is written once instead of being
         # read-modify-written by every branch, and a 256 x 256 output tile pays one epilogue for all 28 taps
@@ -758,7 +824,8 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
         for i in range(nb - 1):
             seq = aspp.convs[i]
             sl = dcat[..., i * mid:(i + 1) * mid]
-            _, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], need_dx=False, dc_out=dcc[i])
+            _, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], need_dx=False, dc_out=dcc[i],
+                                              synced_sums=synced[i], local_sums=local[i])
             grads_convs += [dwi, dgi, dbi]
         wcat = K.concat_tap_weights([packed(cv, dcat.dtype)[1] for cv in convs])
         dx = K.conv_dgrad_multi(dcc, wcat, [(cv.kernel_size[0], cv.padding[0], cv.dilation[0]) for cv in convs],
@@ -767,11 +834,11 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
         for i in range(nb - 1):
             seq = aspp.convs[i]
             sl = dcat[..., i * mid:(i + 1) * mid]
-            dx, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], dx_accum=dx)
+            dx, _, dwi, dgi, dbi = conv_bn_bwd(cfg, states[i], sl, seq[0], seq[1], dx_accum=dx,
+                                               synced_sums=synced[i], local_sums=local[i])
             grads_convs += [dwi, dgi, dbi]
-    pool = aspp.convs[nb - 1]
-    dpv = K.sum_hw(dcat[..., (nb - 1) * mid:]).view(N, 1, 1, mid)
-    dg_, _, dwp, dgp, dbp = conv_bn_bwd(cfg, states[nb - 1], dpv, pool[1], pool[2])
+    dg_, _, dwp, dgp, dbp = conv_bn_bwd(cfg, states[nb - 1], dpv, pool[1], pool[2], synced_sums=synced[nb - 1],
+                                        local_sums=local[nb - 1])
     K.broadcast_hw(dg_.view(N, cin), dx, scale=1.0 / (h * w), accumulate=True)
     grads_convs += [dwp, dgp, dbp]
     grads = grads_convs + [dwj, dgj, dbj, dw3, dg3, db3, dwc, dbias]

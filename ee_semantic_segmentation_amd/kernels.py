@@ -287,6 +287,9 @@ def conv_dgrad_multi(dys, w_cat, geoms, *, accumulate_into=None):
             for s_ in range(k):
                 taps.append((pad - r * dil, pad - s_ * dil, off))      # the data-gradient's source pixel of tap (r, s)
     assert len(taps) == T
+    # c_int32 wraps silently: the byte offsets (branch index x tensor bytes) must fit BEFORE they are packed
+    if any(not (-2 ** 15 < t[0] < 2 ** 15 and -2 ** 15 < t[1] < 2 ** 15 and 0 <= t[2] < 2 ** 31) for t in taps):
+        raise _lib.EesegError("conv_dgrad_multi: tap table entry out of range (shifts 16 bit, source offset < 2 GiB)")
     tab = (C.c_int32 * (3 * T))(*[v for t in taps for v in t])
     if accumulate_into is not None:
         dx = accumulate_into
@@ -396,11 +399,13 @@ def im2col_nchw(x, R, S, stride, pad, kpad, dtype):
 
 
 # ------------------------------------------------------------- batchnorm ----
-def reduce_partials(partials):
-    """[tiles, ...] fp32 -> [...] summed over tiles (fixed order)."""
+def reduce_partials(partials, out=None):
+    """[tiles, ...] fp32 -> [...] summed over tiles (fixed order); `out`: a contiguous fp32 buffer of that shape."""
     tiles = partials.shape[0]
     kc = partials[0].numel()
-    out = torch.empty(partials.shape[1:], dtype=torch.float32, device=partials.device)
+    if out is None:
+        out = torch.empty(partials.shape[1:], dtype=torch.float32, device=partials.device)
+    assert out.is_contiguous() and out.numel() == kc and out.dtype == torch.float32
     ws = workspace(32 * kc * 4, partials.device)
     check(lib().eeseg_bn_reduce_partials(_p(partials), tiles, kc, _p(out), _p(ws), ws.numel(), _stream()),
           "eeseg_bn_reduce_partials")

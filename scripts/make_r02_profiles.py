@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copies the evidence of scripts/evidence_r02.sh (gpurun_out/ev2/) into profiles/ and renders the PMC counter log of the
 conv shapes as profiles/r02_pmc_mfma.md.  Run in the build container after the gpurun call."""
-import json, os, re, shutil, subprocess, sys
+import ast, json, os, re, shutil, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(R, "gpurun_out", "ev2")
 P = os.path.join(R, "profiles")
@@ -24,7 +24,7 @@ for b in log.split("== ")[1:]:
         short = ("conv_pws_kernel" if "conv_pws" in name else "conv_pw_kernel" if "conv_pw" in name else
                  "conv_wgrad_big_kernel" if "wgrad_big" in name else "conv_big_fixup_kernel" if "fixup" in name else
                  "conv_big_kernel" if "conv_big_kernel" in name else name)
-        d = eval(m.group(4))
+        d = ast.literal_eval(m.group(4))
         cnt.setdefault(short, {}).update({k: float(v) for k, v in d.items()})
         raw.append(f"{title:36s} {short:24s} " + " ".join(f"{k} {v}" for k, v in d.items()))
     want = ("conv_wgrad_big_kernel" if title.endswith("wgrad") else "conv_pws_kernel" if "conv_pws_kernel" in cnt else

@@ -43,13 +43,13 @@ def test_batched_progressive_equals_one_image_at_a_time(arch, n, dtype, size, B)
     X = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(5)).to(DEV)
     X *= torch.linspace(0.3, 2.0, B, device=DEV).view(B, 1, 1, 1)          # spread the entropies over the batch
     ents, _ = _all_exit_entropies(net, X, C)
-    # about half of the gate values pass; the threshold sits in the WIDEST gap between neighbouring gate values of the
-    # middle third, so that the decisions do not hinge on the last bits of an entropy (in bf16 the conv launch plan - K-split
-    # tails, pointwise kernel choice - depends on the batch size, so batch 1 and batch B round differently)
-    flat = np.sort(ents.reshape(-1))
-    lo, hi = len(flat) // 3, max(len(flat) // 3 + 2, 2 * len(flat) // 3)
-    k = lo + int(np.argmax(np.diff(flat[lo:hi + 1])))
-    tau = float(0.5 * (flat[k] + flat[k + 1]))
+    # the threshold splits the FIRST gate's values (so the batch leaves through different exits) at the split point that is
+    # farthest from every gate value of every exit: the decisions then do not hinge on the last bits of an entropy (in bf16
+    # the conv launch plan - K-split tails, pointwise kernel choice - depends on the batch size, so batch 1 and batch B
+    # round differently)
+    first_gate = np.sort(ents[0])
+    cands = 0.5 * (first_gate[:-1] + first_gate[1:])
+    tau = float(max(cands, key=lambda t: np.abs(ents - t).min()))
     gap = np.abs(ents - tau).min()
     # ---- one image at a time, everything computed (the reference's semantics) -------------------------------------
     op = eval_ee_deeplabv3(net, img_norm_entropy(C), tau, device=torch.device(DEV))
