@@ -410,6 +410,20 @@ def main():
             del r3
             gc.collect()
             torch.cuda.empty_cache()
+            # the per-GPU shards of the N-GPU strong-scaling runs (global B=32) on THIS one GPU, no collectives: what the
+            # kernels alone allow at N = 4 and N = 8 (the >= 6x target is decided by the small-M kernels first)
+            for bs in (8, 4):
+                r4 = Run(headline[0], headline[1], headline[2], headline[3], bs, "bf16", "ce", False, 1, 0, dev, args)
+                d4, l4, _ = timed(r4, max(args.steps, 20), args.warmup, 1, 1, args.no_graph)
+                n4 = max(args.steps, 20)
+                sec[f"shard_b{bs}"] = {"workload": r4.workload(), "value": bs * n4 / d4, "unit": "images/sec",
+                                       "ms_per_step": d4 / n4 * 1e3, "steps": n4,
+                                       "step_ms_hip_events_median": r4.step_ms_median,
+                                       "ranks_at_global_b32": 32 // bs,
+                                       "kernel_only_speedup_at_that_many_gpus": (32 // bs) * (bs * n4 / d4) / line["value"]}
+                del r4
+                gc.collect()
+                torch.cuda.empty_cache()
         except Exception as exc:          # a secondary figure must never cost the headline line
             sec["error"] = repr(exc)
         line["secondary"] = sec
