@@ -67,8 +67,10 @@ SIGNATURES = {
     "eeseg_bn_eval_scale_shift": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp]),
     "eeseg_bn_apply": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "eeseg_bn_apply_relu_mask": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _i, _vp]),
+    "eeseg_bn_finalize_apply": (_i, [_vp, _i, _vp, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _i, _i,
+                                     _vp]),
     "eeseg_channel_stats": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _i64, _vp]),
-    "eeseg_bn_bwd_reduce": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
+    "eeseg_bn_bwd_reduce": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i64, _vp]),
     "eeseg_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i, _vp, _i, _i64, _i, _i,
                                 _vp, _i, _vp]),
     "eeseg_scale_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp]),

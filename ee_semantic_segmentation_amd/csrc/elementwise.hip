@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const T* dy, int lddy, cons
 // partials[tiles][KC] -> out[seg][KC]: block = 64 columns x 16 row lanes, grid.y = segments
 // of the tile range (a second call folds the segments).  Fixed order -> deterministic.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int tiles, int KC,
-                                                               int tiles_per_seg, float* out) {
+                                                               int tiles_per_seg, float* out, float* out2 = nullptr) {
     __shared__ double sred[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += sred[i][lane];
         out[(long long)blockIdx.y * KC + col] = (float)t;
+        if (out2) out2[(long long)blockIdx.y * KC + col] = (float)t;      // second copy (SyncBN: one goes into the collective)
     }
 }
 
@@ -468,10 +469,19 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 // Column-fixed mapping: the host picks gridDim so that (gridDim.x*256) % (C/EPC) == 0, so a
 // thread owns ONE 16-byte channel chunk for its whole grid-stride loop and keeps the
 // per-channel coefficients in registers (no per-element div/mod or coefficient loads).
+// Optional finalize INSIDE the apply pass (fin.sums != NULL): every thread derives the coefficients of its own 16-byte channel
+// chunk from the (all-reduced) sums - the arithmetic of bn_finalize_kernel, bit for bit - and the first thread of every chunk
+// also writes mean / invstd / scale / shift and updates the running statistics.  Saves the bn_finalize launch between the
+// SyncBN collective and the apply pass (125 launches per step on the critical path of a data-parallel rank).
+struct BnFin {
+    const float* sums; double count; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* mean_invstd; float* scale_shift;
+};
+
 template <typename TI, typename TO, int U>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
-                                                       int C, int relu, unsigned char* mask, int rev) {
+                                                       int C, int relu, unsigned char* mask, int rev, BnFin fin) {
     constexpr int EPC = 16 / (int)sizeof(TI);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -479,8 +489,48 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
     const int c0 = (int)(gid % cpr) * EPC;
     const long long rstep = T / cpr;
     float sc[EPC], sh[EPC];
+    if (fin.sums != nullptr) {
+        // One thread per channel chunk of the BLOCK does the (double precision) arithmetic and shares the coefficients
+        // through LDS: the host makes 256 % cpr == 0 or cpr % 256 == 0 (column-fixed grid), so the block's threads cover
+        // min(256, cpr) distinct chunks, chunk(tid) = chunk(tid % cpr).  Redundant fp64 divisions / square roots in all
+        // 256 threads cost more than the launch this fusion removes.
+        __shared__ float s_sc[256][EPC], s_sh[256][EPC];
+        const int nchunk = cpr < 256 ? cpr : 256;
+        const bool owner = gid < cpr;                        // exactly one thread per channel chunk of the GRID writes the outputs
+        if ((int)threadIdx.x < nchunk) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
+            for (int e = 0; e < EPC; ++e) {
+                const int c = c0 + e;
+                const double mean = (double)fin.sums[c] / fin.count;
+                double var = (double)fin.sums[C + c] / fin.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double invstd = 1.0 / sqrt(var + (double)fin.eps);
+                const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
+                const float sce = (float)(g * invstd), she = (float)(b - mean * g * invstd);
+                s_sc[threadIdx.x][e] = sce;
+                s_sh[threadIdx.x][e] = she;
+                if (owner) {
+                    if (fin.mean_invstd) {
+                        fin.mean_invstd[c] = (float)mean;
+                        fin.mean_invstd[C + c] = (float)invstd;
+                    }
+                    fin.scale_shift[c] = sce;
+                    fin.scale_shift[C + c] = she;
+                    if (fin.running_mean) {
+                        const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                        fin.running_mean[c] = (float)((1.0 - fin.momentum) * fin.running_mean[c] + fin.momentum * mean);
+                        fin.running_var[c] = (float)((1.0 - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sc[e] = s_sc[threadIdx.x % nchunk][e]; sh[e] = s_sh[threadIdx.x % nchunk][e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { sc[e] = ss[c0 + e]; sh[e] = ss[C + c0 + e]; }
+    }
     for (long long r_ = gid / cpr; r_ < rows; r_ += U * rstep) {      // U rows of loads in flight per thread
         long long rr[U];
         bool on[U];
@@ -1064,7 +1114,7 @@ extern "C" int64_t eeseg_colreduce_workspace(int64_t rows, int C) {
 }
 
 static int launch_reduce_partials(const float* partials, int tiles, int KC, float* out, float* scratch,
-                                  hipStream_t st) {
+                                  hipStream_t st, float* out2 = nullptr) {
     const int colblocks = (KC + 63) / 64;
     int segs = 1;
     if (tiles >= 2048 && scratch) {
@@ -1077,10 +1127,10 @@ static int launch_reduce_partials(const float* partials, int tiles, int KC, floa
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, segs), dim3(1024), 0, st, partials, tiles, KC, tps,
                            scratch);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, 1), dim3(1024), 0, st, (const float*)scratch, segs,
-                           KC, segs, out);
+                           KC, segs, out, out2);
     } else {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(colblocks, 1), dim3(1024), 0, st, partials, tiles, KC, tiles,
-                           out);
+                           out, out2);
     }
     return EESEG_OK;
 }
@@ -1131,8 +1181,8 @@ extern "C" int eeseg_bn_eval_scale_shift(const float* gamma, const float* beta, 
 
 static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres, void* y,
                          int ldy, int64_t rows, int C, int relu, int in_dtype, int out_dtype, unsigned char* mask,
-                         void* stream) {
-    EESEG_CHECK(x && y && scale_shift && rows > 0, EESEG_ERR_ARG, "bn_apply: bad argument");
+                         void* stream, BnFin fin = BnFin{nullptr, 1.0, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr}) {
+    EESEG_CHECK(x && y && (scale_shift || fin.sums) && rows > 0, EESEG_ERR_ARG, "bn_apply: bad argument");
     CHECK_ROWS("bn_apply x", x, ldx, C, in_dtype);
     if (residual) CHECK_ROWS("bn_apply residual", residual, ldres, C, in_dtype);
     EESEG_CHECK(((uintptr_t)y & 15) == 0 && ldy >= C && ldy % 4 == 0, EESEG_ERR_ARG, "bn_apply: bad y/ldy");
@@ -1143,25 +1193,25 @@ static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
         if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
     } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
         if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
     } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
         if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<float, float, 4>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<float, float, 2>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
         else hipLaunchKernelGGL((bn_apply_kernel<float, float, 1>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1);
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
     } else {
         EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
     }
@@ -1182,10 +1232,22 @@ extern "C" int eeseg_bn_apply_relu_mask(const void* x, int ldx, const float* sca
                          stream);
 }
 
+extern "C" int eeseg_bn_finalize_apply(const void* x, int ldx, const float* sums, double count, const float* gamma,
+                                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                       float* mean_invstd, float* scale_shift, const void* residual, int ldres, void* y, int ldy,
+                                       void* relu_mask, int64_t rows, int C, int relu, int dtype, void* stream) {
+    EESEG_CHECK(sums && scale_shift && count > 0, EESEG_ERR_ARG, "bn_finalize_apply: bad argument");
+    EESEG_CHECK((running_mean == nullptr) == (running_var == nullptr), EESEG_ERR_ARG,
+                "bn_finalize_apply: running_mean/var must both be given or both be NULL");
+    EESEG_CHECK(!relu_mask || relu, EESEG_ERR_ARG, "bn_finalize_apply: the ReLU mask needs relu");
+    return bn_apply_impl(x, ldx, nullptr, residual, ldres, y, ldy, rows, C, relu, dtype, dtype, (unsigned char*)relu_mask, stream,
+                         BnFin{sums, count, gamma, beta, eps, momentum, running_mean, running_var, mean_invstd, scale_shift});
+}
+
 // launches stage1 via `launch1(grid, rows_per_block, TX, partial_ptr)` then stage 2 when needed
 template <typename L>
 static int two_stage(L&& launch1, int64_t rows, int C, int K, int epc, float* out, void* workspace,
-                     int64_t workspace_bytes, hipStream_t st) {
+                     int64_t workspace_bytes, hipStream_t st, float* out2 = nullptr) {
     const int cpr = C / epc;
     int TX = 32;
     while (TX > cpr) TX >>= 1;
@@ -1204,7 +1266,10 @@ static int two_stage(L&& launch1, int64_t rows, int C, int K, int epc, float* ou
     launch1(dim3(colblocks, rs.blocks), rs.rows_per_block, TX, partials);
     EESEG_LAUNCH_CHECK();
     if (rs.blocks > 1) {
-        launch_reduce_partials(partials, rs.blocks, K * C, out, scratch, st);
+        launch_reduce_partials(partials, rs.blocks, K * C, out, scratch, st, out2);
+        EESEG_LAUNCH_CHECK();
+    } else if (out2) {      // single-stage reduction (tiny tensor): the copy costs one more small launch
+        launch_reduce_partials(out, 1, K * C, out2, nullptr, st);
         EESEG_LAUNCH_CHECK();
     }
     return EESEG_OK;
@@ -1242,7 +1307,8 @@ extern "C" int eeseg_colsum(const void* x, int ldx, int64_t rows, int C, float* 
 
 extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                                    const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
-                                   float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+                                   float* sums, float* sums_copy, int dtype, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
     EESEG_CHECK(dy && x && mean_invstd && sums && rows > 0 && ((relu != 1 && relu != 3) || y) && (relu != 2 || scale_shift) &&
                     relu >= 0 && relu <= 3, EESEG_ERR_ARG, "bn_bwd_reduce: bad argument");
     EESEG_CHECK(relu != 3 || ldy >= C / (16 / eeseg_dtype_size(dtype)), EESEG_ERR_ARG, "bn_bwd_reduce: mask row too short");
@@ -1254,11 +1320,11 @@ extern "C" int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int 
         return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
             hipLaunchKernelGGL((bn_bwd_stage1<bf16_t>), g, dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)y,
                                ldy, (const bf16_t*)x, ldx, mean_invstd, scale_shift, (long long)rows, rpb, C, relu, TX, part);
-        }, rows, C, 2, 8, sums, workspace, workspace_bytes, st);
+        }, rows, C, 2, 8, sums, workspace, workspace_bytes, st, sums_copy);
     return two_stage([&](dim3 g, long long rpb, int TX, float* part) {
         hipLaunchKernelGGL((bn_bwd_stage1<float>), g, dim3(256), 0, st, (const float*)dy, lddy, (const float*)y, ldy,
                            (const float*)x, ldx, mean_invstd, scale_shift, (long long)rows, rpb, C, relu, TX, part);
-    }, rows, C, 2, 4, sums, workspace, workspace_bytes, st);
+    }, rows, C, 2, 4, sums, workspace, workspace_bytes, st, sums_copy);
 }
 
 extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,

@@ -411,8 +411,14 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
             return y, (x, c, mask, mi, count, relu, ss, True)
         return K.bn_apply(c, ss, residual=residual, relu=relu, out=out), (x, c, None, mi, count, relu, ss, True)
     if cfg.sync_active():
+        # SyncBN: partial sums -> ONE collective -> finalize INSIDE the apply pass (eeseg_bn_finalize_apply): no separate
+        # finalize launch between the collective and the pass that waits for it
         sums, count = sync_bn_sums(cfg, K.reduce_partials(part), count)
-        mi, ss = K.bn_finalize(sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
+        bn._pending_batches += 1
+        want_mask = residual is not None and relu
+        y, mask, mi, ss = K.bn_finalize_apply(c, sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
+                                              residual=residual, relu=relu, out=out, want_mask=want_mask)
+        return y, (x, c, mask, mi, count, relu, ss)
     elif part.shape[0] > 2048:      # very many tiles (stem): two-level reduction, then finalize
         mi, ss = K.bn_finalize(K.reduce_partials(part), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean,
                                bn.running_var)
@@ -450,23 +456,24 @@ def conv_bn_fwd_group(cfg, items, frozen=False):
     res = []
     for (x, conv, bn, relu, out), (c, sums, count) in zip(items, pend):
         mom = bn.momentum if bn.momentum is not None else 0.1
-        mi, ss = K.bn_finalize(sums, count * cfg.world(), bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var)
         bn._pending_batches += 1
-        y = K.bn_apply(c, ss, relu=relu, out=out)
+        y, _, mi, ss = K.bn_finalize_apply(c, sums, count * cfg.world(), bn.weight, bn.bias, bn.eps, mom, bn.running_mean,
+                                           bn.running_var, relu=relu, out=out)
         res.append((y, (x, c, None, mi, count * cfg.world(), relu, ss)))
     return res
 
 
-def bn_bwd_local_sums(cfg, st, dy, bn):
+def bn_bwd_local_sums(cfg, st, dy, bn, copy):
     """First half of conv_bn_bwd for a train-mode layer under SyncBN: this rank's (sum g, sum g x_hat) - written into the
-    gradient arena as (dbeta, dgamma) like conv_bn_bwd does - returned as a fresh [2,C] tensor for the collective."""
+    gradient arena as (dbeta, dgamma) like conv_bn_bwd does - and, by the same launch, into `copy` ([2,C] slice of the buffer
+    the collective reduces)."""
     x, c, y, mi, count, relu, ss = st[:7]
     pair = cfg.gview(bn)
     if pair is not None and cfg.accumulate:
-        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss, copy=copy)
         pair.add_(sums)
     else:
-        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
+        sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss, copy=copy)
     return sums
 
 
@@ -485,6 +492,11 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     elif pair is not None and cfg.accumulate:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, scale_shift=ss)
         pair.add_(sums)
+    elif pair is not None and cfg.sync_active() and not frozen:
+        # SyncBN + arena: the reduction writes the local sums (dbeta, dgamma) into the arena AND a second copy for the collective
+        sync_copy = torch.empty_like(pair)
+        K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss, copy=sync_copy)
+        sums = pair
     else:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
@@ -498,7 +510,8 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     elif cfg.sync_active():
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()  # parameter grads stay local (DP averages them)
-        sums = sums.clone() if pair is not None else sums
+        if pair is not None and not cfg.accumulate:
+            sums = sync_copy                 # (accumulate mode: `sums` is a private tensor already)
         if cfg.defer_wgrad:
             work = cfg.all_reduce_begin(sums)
             cfg.run_deferred()               # the layer above's weight gradient fills the collective's latency
@@ -813,8 +826,7 @@ def head_bwd(cfg, state, dlogits, head, dx_init=None):
         dys = [dcat[..., i * mid:(i + 1) * mid] for i in range(nb - 1)] + [dpv]
         flat = torch.empty((nb, 2, mid), dtype=torch.float32, device=dcat.device)
         for i in range(nb):
-            local[i] = bn_bwd_local_sums(cfg, states[i], dys[i], bns[i])
-            flat[i].copy_(local[i])
+            local[i] = bn_bwd_local_sums(cfg, states[i], dys[i], bns[i], flat[i])
         cfg.all_reduce(flat)
         synced = [flat[i] for i in range(nb)]
     if merge:

@@ -466,6 +466,33 @@ def bn_apply(x, scale_shift, *, residual=None, relu=False, out=None, out_dtype=N
     return out
 
 
+def bn_finalize_apply(x, sums, count, gamma, beta, eps, momentum, running_mean, running_var, *, residual=None, relu=False,
+                      out=None, want_mask=False):
+    """bn_finalize + bn_apply in one launch (SyncBN path: `sums` [2,C] come out of the collective).
+    -> (y, mask | None, mean_invstd [2,C], scale_shift [2,C])."""
+    _need_cuda(x, sums)
+    rows, Cc, ldx = rows_ld(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    rows2, C2, ldy = rows_ld(out)
+    assert rows2 == rows and C2 == Cc and out.dtype == x.dtype and sums.shape == (2, Cc) and sums.is_contiguous()
+    ldres = 0
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+        _, _, ldres = rows_ld(residual)
+    mask = None
+    if want_mask:
+        assert relu
+        mask = torch.empty((rows, Cc // (16 // x.element_size())), dtype=torch.uint8, device=x.device)
+    mean_invstd = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    scale_shift = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    check(lib().eeseg_bn_finalize_apply(_p(x), ldx, _p(sums), float(count), _p(gamma), _p(beta), eps, momentum,
+                                        _p(running_mean), _p(running_var), _p(mean_invstd), _p(scale_shift), _p(residual),
+                                        ldres, _p(out), ldy, _p(mask), rows, Cc, int(relu), _dt(x), _stream()),
+          "eeseg_bn_finalize_apply")
+    return out, mask, mean_invstd, scale_shift
+
+
 def channel_stats(x):
     rows, Cc, ldx = rows_ld(x)
     sums = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
@@ -495,15 +522,17 @@ def _relu_mode(relu, y, scale_shift):
     return 2 if (y is None and scale_shift is not None) else 1
 
 
-def bn_bwd_reduce(dy, y, x, mean_invstd, relu, out=None, scale_shift=None):
+def bn_bwd_reduce(dy, y, x, mean_invstd, relu, out=None, scale_shift=None, copy=None):
+    """-> sums [2,C] (written into `out` when given); `copy`: a second contiguous [2,C] fp32 buffer that receives the same sums."""
     rows, Cc, lddy = rows_ld(dy)
     _, _, ldx = rows_ld(x)
     ldy = rows_ld(y)[2] if y is not None else 0
     sums = out if out is not None else torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     assert sums.is_contiguous() and sums.shape == (2, Cc) and sums.dtype == torch.float32
     ws = workspace(lib().eeseg_colreduce_workspace(rows, Cc), x.device)
+    assert copy is None or (copy.is_contiguous() and copy.numel() == 2 * Cc and copy.dtype == torch.float32)
     check(lib().eeseg_bn_bwd_reduce(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), _p(scale_shift), rows, Cc,
-                                    _relu_mode(relu, y, scale_shift), _p(sums), _dt(x), _p(ws), ws.numel(),
+                                    _relu_mode(relu, y, scale_shift), _p(sums), _p(copy), _dt(x), _p(ws), ws.numel(),
                                     _stream()), "eeseg_bn_bwd_reduce")
     return sums
 

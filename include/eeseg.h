@@ -195,6 +195,14 @@ int eeseg_bn_apply(const void* x, int ldx, const float* scale_shift, const void*
  * residual input cannot recompute the mask from x alone: with the byte mask their backward streams 1/16 of y. */
 int eeseg_bn_apply_relu_mask(const void* x, int ldx, const float* scale_shift, const void* residual, int ldres,
                              void* y, int ldy, void* relu_mask, int64_t rows, int C, int dtype, void* stream);
+/* bn_finalize + bn_apply(_relu_mask) in ONE launch: the coefficients are derived inside the apply pass from the [2][C]
+ * sums (the arithmetic of eeseg_bn_finalize, bit for bit; mean_invstd / scale_shift / running statistics are written as
+ * there).  For the SyncBN path, where the sums come out of a collective and a separate finalize launch would sit on the
+ * critical path of every layer (torch BatchNorm2d reached from from_deepv3_new.py:146-151).  relu_mask optional. */
+int eeseg_bn_finalize_apply(const void* x, int ldx, const float* sums, double count, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, float* mean_invstd,
+                            float* scale_shift, const void* residual, int ldres, void* y, int ldy, void* relu_mask,
+                            int64_t rows, int C, int relu, int dtype, void* stream);
 /* per-channel sums of x and x^2 over rows (tensors that did not come out of the
  * conv epilogue, e.g. the pooled ASPP branch): sums[2][C] */
 int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype, void* workspace,
@@ -203,10 +211,12 @@ int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums
  * relu: 0 no activation; 1 mask = (y > 0) read from the stored output; 2 mask recomputed as
  * (x*scale+shift > 0) from scale_shift[2][C] - for layers without a residual input this saves the
  * read of y (one of the 3-4 streamed tensors); 3 `y` points at the byte mask of eeseg_bn_apply_relu_mask and
- * `ldy` is its row length in bytes (same in eeseg_bn_bwd_apply). */
+ * `ldy` is its row length in bytes (same in eeseg_bn_bwd_apply).  sums_copy (optional): a second [2][C] buffer that
+ * receives the same sums - under SyncBN one copy stays local (dbeta, dgamma in the gradient arena), the other goes into
+ * the collective. */
 int eeseg_bn_bwd_reduce(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
                         const float* mean_invstd, const float* scale_shift, int64_t rows, int C, int relu,
-                        float* sums, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+                        float* sums, float* sums_copy, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* backward, step 2: dx = gamma*invstd*(g - sums0/count - xhat*sums1/count);
  * dres (optional) = g.  dgamma = sums1, dbeta = sums0 (taken by the host). */
 int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,

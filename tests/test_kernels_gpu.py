@@ -537,6 +537,39 @@ def test_conv_256_tile_kernel_vs_torch(case):
     close(dw.permute(0, 3, 1, 2), w.grad, 4e-3, "conv wgrad")
 
 
+def test_bn_finalize_apply_and_dual_output_reduce_equal_the_separate_launches():
+    """SyncBN path: eeseg_bn_finalize_apply (finalize inside the apply pass) must equal eeseg_bn_finalize followed by
+    eeseg_bn_apply / _relu_mask BIT FOR BIT (outputs, masks, coefficients, running statistics), and eeseg_bn_bwd_reduce's
+    optional second output must be a copy of the first."""
+    g = torch.Generator().manual_seed(33)
+    for dtype in DTYPES:
+        for rows_shape, Cc, relu, use_res in [((2, 17, 19), 64, True, True), ((4, 33, 33), 256, True, False),
+                                              ((1, 9, 9), 1024, False, False), ((3, 8, 8), 128, True, True)]:
+            x = (torch.randn(*rows_shape, Cc, generator=g) * 2 + 0.3).to(DEV, dtype)
+            res = torch.randn(*rows_shape, Cc, generator=g).to(DEV, dtype) if use_res else None
+            rows = x.numel() // Cc
+            xf = x.float().reshape(rows, Cc)
+            sums = torch.stack([xf.sum(0), (xf * xf).sum(0)]).contiguous()
+            gamma, beta = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV)
+            rm1, rv1 = torch.randn(Cc, device=DEV), torch.rand(Cc, device=DEV) + 0.5
+            rm2, rv2 = rm1.clone(), rv1.clone()
+            mi1, ss1 = K.bn_finalize(sums, rows, gamma, beta, 1e-5, 0.1, rm1, rv1)
+            if use_res and relu:
+                y1, m1 = K.bn_apply(x, ss1, residual=res, relu=True, want_mask=True)
+            else:
+                y1, m1 = K.bn_apply(x, ss1, residual=res, relu=relu), None
+            y2, m2, mi2, ss2 = K.bn_finalize_apply(x, sums, rows, gamma, beta, 1e-5, 0.1, rm2, rv2, residual=res, relu=relu,
+                                                   want_mask=m1 is not None)
+            assert torch.equal(y1, y2) and torch.equal(mi1, mi2) and torch.equal(ss1, ss2)
+            assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+            assert (m1 is None and m2 is None) or torch.equal(m1, m2)
+            dy = torch.randn(*rows_shape, Cc, generator=g).to(DEV, dtype)
+            a = K.bn_bwd_reduce(dy, None, x, mi1, relu, scale_shift=ss1)
+            out, cp = torch.empty(2, Cc, device=DEV), torch.empty(2, Cc, device=DEV)
+            K.bn_bwd_reduce(dy, None, x, mi1, relu, out=out, scale_shift=ss1, copy=cp)
+            assert torch.equal(a, out) and torch.equal(out, cp)
+
+
 def test_bn_reduce_finalize_fused_equals_two_step():
     g = torch.Generator().manual_seed(21)
     for tiles, Cc in [(1, 64), (37, 256), (529, 2048), (8257, 64)]:
