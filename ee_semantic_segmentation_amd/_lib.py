@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads torch's bundled libamdhip64 FIRST so libeeseg binds to the same HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeeseg.so")
+# EESEG_LIB: another build of the SAME ABI (same-box A/B of two builds: scripts/ab_builds.sh); default = the in-tree library
+LIB_PATH = os.environ.get("EESEG_LIB") or os.path.join(_HERE, "libeeseg.so")
 
 F32, BF16 = 0, 1
 

@@ -1954,6 +1954,7 @@ extern int g_ce_span;     // loss.hip
 extern int g_bn_reverse;  // elementwise.hip
 extern int g_bn_rows;
 extern int g_bn_bwd_rows;
+extern int g_bn_nt;
 extern int g_colreduce_blocks;
 
 extern int g_last_wgrad_kernel;   // conv_wgrad.hip
@@ -1999,6 +2000,10 @@ extern "C" int eeseg_set_option(int key, int value) {
     }
     if (key == EESEG_OPT_BN_BWD_ROWS && (value == 1 || value == 2 || value == 4)) {
         g_bn_bwd_rows = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_BN_NT && value >= 0 && value <= 3) {
+        g_bn_nt = value;
         return EESEG_OK;
     }
     if (key == EESEG_OPT_BN_ROWS && (value == 1 || value == 2 || value == 4)) {
@@ -2058,6 +2063,7 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_BN_REVERSE: return g_bn_reverse;
         case EESEG_OPT_BN_ROWS: return g_bn_rows;
         case EESEG_OPT_BN_BWD_ROWS: return g_bn_bwd_rows;
+        case EESEG_OPT_BN_NT: return g_bn_nt;
         case EESEG_OPT_COLREDUCE_BLOCKS: return g_colreduce_blocks;
         case EESEG_OPT_CONV_SPLIT_MIN_K: return g_conv_big_split_min_k;
         case EESEG_OPT_CONV_PW_MAX_K: return g_conv_pw_max_k;

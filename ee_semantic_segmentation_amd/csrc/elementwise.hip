@@ -7,6 +7,7 @@
 
 int g_bn_reverse = 0;               // EESEG_OPT_BN_REVERSE: bit 0 bn_apply, bit 1 bn_bwd_apply sweep rows from the end
 
+int g_bn_nt = 0;                     // EESEG_OPT_BN_NT: bit 0 bn_apply, bit 1 bn_bwd_apply read their dead-after-this-pass inputs nontemporally
 int g_colreduce_blocks = 512;        // EESEG_OPT_COLREDUCE_BLOCKS: blocks a column reduction aims at in all (0 = up to 1024 row blocks per
                                      // column block: 8192 blocks and 16 MB of partial sums for a 2048-channel tensor; 512: +0.5..1.4 % end to end)
 int g_bn_rows = 2;                  // EESEG_OPT_BN_ROWS: rows of loads in flight per thread in bn_apply (1, 2, 4)
@@ -22,6 +23,14 @@ template <typename T> struct Vec {
 
 template <typename T> __device__ __forceinline__ Vec<T> ld16(const T* p) {
     Vec<T> v; v.q = *reinterpret_cast<const i32x4*>(p); return v;
+}
+// streamed-once loads: a nontemporal hint keeps a tensor that is dead after this pass from displacing the one the next
+// kernel is about to read (EESEG_OPT_BN_NT)
+template <typename T> __device__ __forceinline__ Vec<T> ld16s(const T* p, bool nt) {
+    Vec<T> v;
+    if (nt) v.q = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
+    else v.q = *reinterpret_cast<const i32x4*>(p);
+    return v;
 }
 template <typename T> __device__ __forceinline__ void st16(T* p, const Vec<T>& v) {
     *reinterpret_cast<i32x4*>(p) = v.q;
@@ -478,10 +487,10 @@ struct BnFin {
     float* running_mean; float* running_var; float* mean_invstd; float* scale_shift;
 };
 
-template <typename TI, typename TO, int U>
+template <typename TI, typename TO, int U, bool FIN>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, const float* __restrict__ ss,
                                                        const TI* res, int ldres, TO* y, int ldy, long long rows,
-                                                       int C, int relu, unsigned char* mask, int rev, BnFin fin) {
+                                                       int C, int relu, unsigned char* mask, int rev, BnFin fin, int nt) {
     constexpr int EPC = 16 / (int)sizeof(TI);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
     const int c0 = (int)(gid % cpr) * EPC;
     const long long rstep = T / cpr;
     float sc[EPC], sh[EPC];
-    if (fin.sums != nullptr) {
+    if constexpr (FIN) {
         // One thread per channel chunk of the BLOCK does the (double precision) arithmetic and shares the coefficients
         // through LDS: the host makes 256 % cpr == 0 or cpr % 256 == 0 (column-fixed grid), so the block's threads cover
         // min(256, cpr) distinct chunks, chunk(tid) = chunk(tid % cpr).  Redundant fp64 divisions / square roots in all
@@ -541,8 +550,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TI* x, int ldx, con
             on[u] = q < rows;
             rr[u] = rev ? rows - 1 - q : q;      // rev: sweep from the end (the rows the producer wrote last)
             if (on[u]) {
-                v2[u] = ld16(x + rr[u] * ldx + c0);
-                if (res) rv2[u] = ld16(res + rr[u] * ldres + c0);
+                v2[u] = ld16s(x + rr[u] * ldx + c0, nt & 1);
+                if (res) rv2[u] = ld16s(res + rr[u] * ldres + c0, nt & 1);
             }
         }
         if (U > 1) __builtin_amdgcn_sched_barrier(0);      // every row's loads issued before the first is consumed
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, float inv_count, T* dx,
                                                            int lddx, T* dres, int lddres, long long rows, int C,
-                                                           int relu, const float* __restrict__ scale_shift, int rev) {
+                                                           int relu, const float* __restrict__ scale_shift, int rev, int nt) {
     constexpr int EPC = 16 / (int)sizeof(T);
     const int cpr = C / EPC;
     const long long gid = blockIdx.x * 256ll + threadIdx.x;
@@ -628,10 +637,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
             on[u] = q < rows;
             rr[u] = rev ? rows - 1 - q : q;      // rev: against the direction of the reduction pass before
             if (on[u]) {
-                g[u] = ld16(dy + rr[u] * lddy + c0);
+                g[u] = ld16s(dy + rr[u] * lddy + c0, nt & 2);
                 if (relu == 1) yv[u] = ld16(y + rr[u] * ldy + c0);
                 if (relu == 3) mb[u] = bmask[rr[u] * ldy + c0 / EPC];
-                if (MODE == 0) xv[u] = ld16(x + rr[u] * ldx + c0);
+                if (MODE == 0) xv[u] = ld16s(x + rr[u] * ldx + c0, nt & 2);
             }
         }
         if (U > 1) __builtin_amdgcn_sched_barrier(0);      // every row's loads issued before the first is consumed
@@ -1192,26 +1201,35 @@ static int bn_apply_impl(const void* x, int ldx, const float* scale_shift, const
     const int g = colfixed_grid(rows, C / epc);
     if (in_dtype == EESEG_BF16 && out_dtype == EESEG_BF16) {
         EESEG_CHECK(ldy % 8 == 0, EESEG_ERR_ARG, "bn_apply: ldy must be a multiple of 8");
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
+        if (g_bn_rows == 4) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 4, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 4, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else if (g_bn_rows == 2) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 2, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 2, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 1, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, bf16_t, 1, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (bf16_t*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
     } else if (in_dtype == EESEG_BF16 && out_dtype == EESEG_F32) {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
+        if (g_bn_rows == 4) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 4, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 4, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else if (g_bn_rows == 2) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 2, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 2, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 1, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, float, 1, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                           scale_shift, (const bf16_t*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
     } else if (in_dtype == EESEG_F32 && out_dtype == EESEG_F32) {
-        if (g_bn_rows == 4) hipLaunchKernelGGL((bn_apply_kernel<float, float, 4>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else if (g_bn_rows == 2) hipLaunchKernelGGL((bn_apply_kernel<float, float, 2>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
-        else hipLaunchKernelGGL((bn_apply_kernel<float, float, 1>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
-                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin);
+        if (g_bn_rows == 4) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<float, float, 4, true>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<float, float, 4, false>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else if (g_bn_rows == 2) { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<float, float, 2, true>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<float, float, 2, false>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
+        else { if (fin.sums) hipLaunchKernelGGL((bn_apply_kernel<float, float, 1, true>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); else hipLaunchKernelGGL((bn_apply_kernel<float, float, 1, false>), dim3(g), dim3(256), 0, st, (const float*)x, ldx,
+                           scale_shift, (const float*)residual, ldres, (float*)y, ldy, (long long)rows, C, relu, mask, g_bn_reverse & 1, fin, g_bn_nt); }
     } else {
         EESEG_CHECK(false, EESEG_ERR_ARG, "bn_apply: unsupported dtype pair %d -> %d", in_dtype, out_dtype);
     }
@@ -1346,24 +1364,24 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
     if (dtype == EESEG_BF16) {
         if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
-                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
         else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
-                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 0, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mean_invstd, gamma, sums, inv, (bf16_t*)dx,
-                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
     }
     else {
         if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
-                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
         else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
-                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 0, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
-                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1);
+                           (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
     }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
@@ -1384,29 +1402,29 @@ extern "C" int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int 
         if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 4>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
         else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 2>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, 1, 1>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, lddy,
                            (const bf16_t*)y, ldy, (const bf16_t*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
     }
     else {
         if (g_bn_bwd_rows == 4) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 4>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
         else if (g_bn_bwd_rows == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 2>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 1, 1>), dim3(g), dim3(256), 0, st, (const float*)dy, lddy,
                            (const float*)y, ldy, (const float*)nullptr, 0, (const float*)nullptr, scale,
                            (const float*)nullptr, 0.f, (float*)dx, lddx, (float*)dres, lddres, (long long)rows, C, relu ? 1 : 0,
-                           (const float*)nullptr, 0);
+                           (const float*)nullptr, 0, 0);
     }
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;

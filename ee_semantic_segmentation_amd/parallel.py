@@ -8,8 +8,9 @@ buckets that fill in reverse-layer order while backward is still running
 (classifier / deep heads first); a bucket is a plain slice of the gradient arena,
 reduced on the package's own lane stream beside the rest of backward; ``finish()``
 makes the compute stream wait before the optimizer step.  xGMI is point-to-point, so
-buckets are large (default 64 MiB) - few, big collectives keep every link busy instead
-of paying per-call latency.  BatchNorm statistics (engine.Config.sync_bn) and the CE
+buckets are large (default 32 MiB, SURVEY section 5: 25-50 MB) - few, big collectives keep
+every link busy instead of paying per-call latency, while the LAST bucket (it ends with the stem
+and is launched when backward ends, so its all-reduce is exposed) stays small.  BatchNorm statistics (engine.Config.sync_bn) and the CE
 valid-pixel count are all-reduced inside the respective layers.  No c10d ``Work`` is
 ever created for a device tensor: comm.py says why.
 """
@@ -213,7 +214,7 @@ class ArenaReducer:
     last unit it covers has finished its backward, overlapping with the rest of
     backward.  No flatten / unflatten copies."""
 
-    def __init__(self, net, bucket_bytes=64 << 20, group=None, average=True, reserve_cus=None):
+    def __init__(self, net, bucket_bytes=32 << 20, group=None, average=True, reserve_cus=None):
         self.cfg, self.group, self.average = net.cfg, group, average
         # CUs left to the RCCL kernels while buckets are in flight: the 256-tile conv kernels run one block per CU and
         # size their rounds / K splits for the CUs they can get, so a launch planned for 256 CUs needs a second round

@@ -40,7 +40,8 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_CONV_SWP = 19 /* 256x256 conv kernel, 16x16x32 form: 1 (default) = software-pipelined K loop (the LDS reads of phase p+1 sit between the MFMAs of phase p, the eight waves in lockstep, one barrier per phase); 0 = two wave groups half a phase apart; same bits */,
+enum { EESEG_OPT_BN_NT = 20 /* bit 0: bn_apply, bit 1: bn_bwd_apply load the tensors that are dead after the pass (conv output / residual; dy / conv output) with a nontemporal hint (default 0) */,
+       EESEG_OPT_CONV_SWP = 19 /* 256x256 conv kernel, 16x16x32 form: 1 (default) = software-pipelined K loop (the LDS reads of phase p+1 sit between the MFMAs of phase p, the eight waves in lockstep, one barrier per phase); 0 = two wave groups half a phase apart; same bits */,
        EESEG_OPT_BN_BWD_ROWS = 18 /* bn_bwd_apply / scale_act_bwd: rows whose loads a thread keeps in flight (1 = default, 2, 4) */,
        EESEG_OPT_CONV_MFMA16 = 17 /* 256x256 conv kernel: 1 (default) = v_mfma_f32_16x16x32_bf16, 0 = v_mfma_f32_32x32x16_bf16 (same tile, same LDS image, same cycles per FLOP; the chip holds a higher clock on the 16x16 shape: 3-7 % faster) */,
        EESEG_OPT_CONV_COUT_GROUP = 16 /* 256x256 conv kernel, layers with more cout tiles than this: the 32 CUs of an XCD work on `value` cout tiles x 32/value pixel tiles at a time (1, 2, 4, 8; default 0 = all cout tiles of few pixel tiles; an A/B switch, measured neutral on the 8-cout-tile layers) */,
