@@ -198,3 +198,76 @@ def test_grad_arena_views_have_the_parameter_layout():
             kv.copy_(torch.arange(kv.numel(), dtype=torch.float32).view(kv.shape))
             assert torch.equal(p.grad, kv[:p.shape[0]].permute(0, 3, 1, 2)), name     # same bytes, same element order
     assert n1x1 >= 40
+
+
+def test_shard_sampler_partitions_every_global_batch():
+    """parallel.ShardSampler (SURVEY 8e "DistributedSampler-style seeding"): for every epoch the ranks' index streams are the
+    rank-major slices of the SAME global batches one process would train on; the ragged last batch is dropped when N > 1 and
+    kept (the reference's drop_last=False) for one process; epochs reshuffle."""
+    from ee_semantic_segmentation_amd.parallel import ShardSampler, eval_shard
+    n, B = 23, 8
+    for world in (2, 4):
+        b = B // world
+        for epoch in (0, 1, 5):
+            one = ShardSampler(n, B, 1, 0, seed=3)
+            one.set_epoch(epoch)
+            whole = list(one)
+            assert sorted(whole) == list(range(n)) and len(one) == n
+            ranks = []
+            for r in range(world):
+                s = ShardSampler(n, B, world, r, seed=3)
+                s.set_epoch(epoch)
+                ranks.append(list(s))
+                assert len(ranks[-1]) == len(s) == (n // B) * b
+            for k in range(n // B):                       # global batch k = concatenation of the ranks' k-th local batches
+                got = [i for r in range(world) for i in ranks[r][k * b:(k + 1) * b]]
+                assert got == whole[k * B:(k + 1) * B], (world, epoch, k)
+        a, c = ShardSampler(n, B, 1, 0, seed=3), ShardSampler(n, B, 1, 0, seed=3)
+        a.set_epoch(1); c.set_epoch(2)
+        assert list(a) != list(c)
+    with pytest.raises(ValueError):
+        ShardSampler(n, 6, 4, 0)
+    ds = list(range(11))
+    parts = [list(eval_shard(ds, 3, r)) for r in range(3)]
+    assert sorted(i for p in parts for i in p) == ds and [len(p) for p in parts] == [4, 4, 3]
+    assert eval_shard(ds, 1, 0) is ds
+
+
+def _counter_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from ee_semantic_segmentation_amd import engine as E
+        from ee_semantic_segmentation_amd.eval_mIoU import reduce_counters
+        from ee_semantic_segmentation_amd.parallel import dp_info
+        cfg = E.Config()
+        cfg.collective = lambda t, group: dist.all_reduce(t, group=group)      # a transport is attached (as init_data_parallel does)
+        net = SimpleNamespace(cfg=cfg, parameters=lambda: iter([torch.zeros(1)]))
+        assert dp_info(net) == (world, rank)
+        g = torch.Generator().manual_seed(70 + rank)
+        accs = [SimpleNamespace(accumulator=torch.randint(0, 1 << 22, (3, 5), generator=g).float()) for _ in range(2)]
+        mine = [a.accumulator.clone() for a in accs]
+        reduce_counters(net, accs)
+        q.put((rank, [m.tolist() for m in mine], [a.accumulator.tolist() for a in accs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_miou_counters_are_summed_over_the_ranks_once_per_evaluation():
+    """eval_mIoU.reduce_counters ("all-reduce [E,3,C] fp32 counters once per eval"): every rank ends with the
+    exact integer sum of the ranks' per-exit (TP, FP, FN) accumulators (fp64 on the wire), world 2 over gloo."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_counter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (torch.tensor(res[0][1], dtype=torch.float64) + torch.tensor(res[1][1], dtype=torch.float64))
+    for _, _, got in res:
+        assert torch.equal(torch.tensor(got, dtype=torch.float64), want)
