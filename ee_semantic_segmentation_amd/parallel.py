@@ -144,6 +144,22 @@ def init_data_parallel(net, group=None, sync_bn=True, broadcast=True, transport=
     if transport is not None:
         cfg.collective, cfg.gatherer = transport
     elif cfg.comm is None:
+        # Communicator creation is COLLECTIVE (ncclCommInitRank blocks until every rank has joined): a rank that cannot even
+        # bind librccl must not leave the others waiting forever.  So the non-collective part is checked on every rank first
+        # and the verdict is agreed on over the rendezvous group (host tensors: any backend that moves them, i.e. gloo).
+        ok, why = 1, ""
+        try:
+            C_.rccl_version()
+        except Exception as exc:                   # noqa: BLE001 - whatever the loader says is the message
+            ok, why = 0, repr(exc)
+        if world > 1 and dist.get_backend(group) != "nccl":
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                raise RuntimeError("RCCL cannot be bound on at least one rank of the job (this rank: "
+                                   + (why or "ok") + "); no communicator was created on any rank")
+        elif not ok:
+            raise RuntimeError("RCCL cannot be bound: " + why)
         cfg.comm = C_.DataParallelComm(group, next(net.parameters()).device)
     cfg.sync_bn = bool(sync_bn)
     if broadcast:
