@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# the hosts of this pool support dmabuf IPC only: without this RCCL's cross-process buffer sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (it is exported on the boxes already; kept here so a hand-built env works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 

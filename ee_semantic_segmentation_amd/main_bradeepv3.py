@@ -6,6 +6,8 @@ import argparse
 import errno
 import os
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes), before the HIP runtime starts
+
 import torch
 
 from . import branchy_seg_losses as BSL
