@@ -46,7 +46,10 @@ def _build(loss_name):
         crit = BrXEntropyLoss(ignore_index=CFG["C"], b_reduction="sum", n_exits=2)
     else:
         from ee_semantic_segmentation_amd.branchy_seg_losses import LovaszSoftmax
-        crit = LovaszSoftmax(ignore=CFG["C"], n_branches=1)
+        # "lovasz": per_image=False, all pixels of the batch ranked jointly -> exact mode all-gathers logits and labels;
+        # "lovasz_pi": per_image=True, every image ranked alone -> the mean over a rank's images, averaged over equal shards,
+        # IS the batch loss: no gather (branchy_seg_losses.LovaszSoftmax.forward)
+        crit = LovaszSoftmax(ignore=CFG["C"], n_branches=1, per_image=(loss_name == "lovasz_pi"))
     return net, crit, X, y
 
 
@@ -105,7 +108,7 @@ def _child(rank, port, loss_name, path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("loss_name", ["ce", "lovasz"])
+@pytest.mark.parametrize("loss_name", ["ce", "lovasz", "lovasz_pi"])
 def test_two_ranks_equal_one_process_on_the_whole_batch(loss_name):
     net, crit, X, y = _build(loss_name)
     whole = _step(net, crit, X, y)
