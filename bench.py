@@ -145,6 +145,7 @@ class Run:
         net.train()
         # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
         # HIP graph and every later call is a replay
+        self.reserve_cus = reducer.reserve_cus if reducer.active else 0
         self.runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2,
                                        use_graph=not args.no_graph and net.cfg.collective is None)
         self.net = net
@@ -272,7 +273,7 @@ def main():
     ap.add_argument("--no-sync-bn", action="store_true", help="N>1: local-batch BatchNorm instead of SyncBN")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="N>1: CUs the conv launch plans leave to RCCL while gradient buckets are in flight (default: "
-                         "EESEG_RCCL_RESERVE_CUS or 0)")
+                         "EESEG_RCCL_RESERVE_CUS, else 32 from 8 ranks on and 0 below - parallel.ArenaReducer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -371,6 +372,7 @@ def main():
                            "collectives": ("RCCL %d via libeeseg, 2 communicators, package-owned lanes" % _rccl_version())
                            if run.net.cfg.comm is not None else
                            ("REHEARSAL: staged through the host over gloo - not a measurement" if run.net.cfg.collective else None),
+                           "reserve_cus": run.reserve_cus,
                            "flop_per_image": flop_img, "loss_last_step": loss_val,
                            "splits": list(run.net.split_names)},
                 "roofline": roof}

@@ -234,8 +234,12 @@ class ArenaReducer:
         self.cfg, self.group, self.average = net.cfg, group, average
         # CUs left to the RCCL kernels while buckets are in flight: the 256-tile conv kernels run one block per CU and
         # size their rounds / K splits for the CUs they can get, so a launch planned for 256 CUs needs a second round
-        # when a collective holds a few of them.  0 = plan for the whole chip (default; EESEG_RCCL_RESERVE_CUS).
-        self.reserve_cus = int(os.environ.get("EESEG_RCCL_RESERVE_CUS", "0")) if reserve_cus is None else reserve_cus
+        # when a collective holds a few of them.  Measured on one GPU with a stand-in for the collective's resident workgroups
+        # (scripts/contention_probe.py): at 4 images per GPU planning for 224 CUs costs nothing and gives
+        # back half of what the held CUs cost, at 8 images per GPU it costs 2 % and wins 1.3 % - so the default is 32 from
+        # 8 ranks on (the metric's 4-image shards) and 0 (the whole chip) below.  EESEG_RCCL_RESERVE_CUS overrides.
+        self._reserve_arg = reserve_cus
+        self.reserve_cus = 0
         self._reserved = False
         self.arena = net.cfg.arena
         if self.arena is None:
@@ -249,6 +253,15 @@ class ArenaReducer:
         # GPU exercise the RCCL-inside-HIP-graph path the multi-GPU bench relies on)
         forced = os.environ.get("EESEG_FORCE_ALLREDUCE") == "1"
         self.active = self.world > 1 or (forced and (self.comm is not None or dist.is_initialized()))
+        env = os.environ.get("EESEG_RCCL_RESERVE_CUS")
+        if self._reserve_arg is not None:
+            self.reserve_cus = int(self._reserve_arg)
+        elif env is not None:
+            self.reserve_cus = int(env)
+        else:
+            self.reserve_cus = 32 if self.world >= 8 else 0
+        if not 0 <= self.reserve_cus <= 192:
+            raise ValueError(f"reserve_cus = {self.reserve_cus}: 0 .. 192")
         self.buckets = []            # (first unit, last unit, start, end)
         u0, start = 0, 0
         for u, (a, b) in enumerate(self.arena.unit_ranges):
