@@ -308,6 +308,36 @@ def test_upsample_ce_fwd_bwd(hw, HW, Cc):
     assert dlr[..., Cc:].abs().max().item() == 0
 
 
+def test_multi_exit_ce_edge_cases():
+    """The degenerate inputs of the reference's per-exit CrossEntropyLoss(ignore_index=C) (my_pixelwise_xentropy.py:11-14), as torch
+    itself answers them: a batch of void pixels only -> NaN loss (0 / 0) with ZERO gradients; exactly one valid pixel; one image of odd
+    size; targets with the channel dim kept ([B,1,H,W], B-7)."""
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    gen = torch.Generator().manual_seed(23)
+    for name, shape, fill in [("all void", (2, 2, 4, 9, 11), "void"), ("one valid pixel", (2, 2, 4, 9, 11), "one"),
+                              ("one odd image", (3, 1, 5, 37, 53), "rand")]:
+        E_, B, Cc, H, W = shape
+        y = torch.randn(*shape, generator=gen) * 2
+        if fill == "rand":
+            t = torch.randint(0, Cc + 1, (B, 1, H, W), generator=gen)
+        else:
+            t = torch.full((B, 1, H, W), Cc)
+            if fill == "one":
+                t[1, 0, 4, 7] = 2
+        yr = y.clone().requires_grad_(True)
+        want = sum(F.cross_entropy(yr[e], t[:, 0], ignore_index=Cc) for e in range(E_))
+        want.backward()
+        yd = y.clone().to(DEV).requires_grad_(True)
+        got = BrXEntropyLoss(ignore_index=Cc, b_reduction="sum", n_exits=E_)(yd, t.to(DEV))
+        got.backward()
+        if fill == "void":
+            assert torch.isnan(want) and torch.isnan(got), (name, want, got)
+            assert yr.grad.abs().max().item() == 0 and yd.grad.abs().max().item() == 0, name
+        else:
+            assert abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item())), (name, got.item(), want.item())
+            close(yd.grad, yr.grad, 2e-5, f"ce edge grad {name}")
+
+
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_reference_golden_through_hip(path):
     """The golden vectors were produced by the reference's own loss / metric code;
