@@ -11,7 +11,7 @@ import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 out = sys.argv[2] if len(sys.argv) > 2 else None
 dev = torch.device("cuda", 0)
-args = argparse.Namespace(overlap_wgrad=0, reserve_cus=None, no_graph=False)
+args = argparse.Namespace(overlap_wgrad=0, reserve_cus=None, no_graph=False, dp_transport="rccl")
 NB = 4                                                    # distinct batches, cycled
 
 
