@@ -9,8 +9,10 @@ import os
 import torch  # noqa: F401  (loads torch's bundled libamdhip64 FIRST so libeeseg binds to the same HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EESEG_LIB: another build of the SAME ABI (same-box A/B of two builds: scripts/ab_builds.sh); default = the in-tree library
+# EESEG_LIB: another build of the SAME ABI (same-box A/B of two builds); default = the in-tree library.  lib() refuses a
+# library whose eeseg_version() differs from ABI_VERSION: the ctypes signatures below are written for exactly that ABI
 LIB_PATH = os.environ.get("EESEG_LIB") or os.path.join(_HERE, "libeeseg.so")
+ABI_VERSION = 104      # bumped with every signature / struct change of include/eeseg.h (csrc/api.hip returns the same number)
 
 F32, BF16 = 0, 1
 
@@ -74,6 +76,10 @@ SIGNATURES = {
     "eeseg_bn_bwd_reduce": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i64, _vp]),
     "eeseg_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i, _vp, _i, _i64, _i, _i,
                                 _vp, _i, _vp]),
+    "eeseg_bn_bwd_coop_ok": (_i, [_i64, _i, _i]),
+    "eeseg_bn_bwd_coop_workspace": (_i64, []),
+    "eeseg_bn_bwd_coop": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i,
+                               _vp, _i64, _vp, _vp]),
     "eeseg_scale_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp]),
     "eeseg_maxpool3x3s2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -130,6 +136,10 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension is the product and there is no fallback. "
                 "Build it with `python -m ee_semantic_segmentation_amd.build`.")
         l = C.CDLL(LIB_PATH)
+        l.eeseg_version.restype = C.c_int
+        if l.eeseg_version() != ABI_VERSION:
+            raise EesegError(f"{LIB_PATH} implements ABI {l.eeseg_version()}, this package binds ABI {ABI_VERSION}: "
+                             "rebuild it with `python -m ee_semantic_segmentation_amd.build`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

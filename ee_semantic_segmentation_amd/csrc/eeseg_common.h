@@ -80,6 +80,61 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// ---- in-launch barrier among a GROUP of co-resident blocks (one episode per group and launch) ------------------
+// For kernels whose whole grid is resident (the host sizes the grid to <= one block per CU it may count on); a group =
+// the blocks that exchange data (all of them = a grid barrier; the row blocks of one channel group = the BatchNorm
+// backward below: fewer arrivals per counter and no wait for unrelated blocks).
+// Fence-free form of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms" (first row of the sc1
+// table): CONTRACT - every byte another block reads after the barrier was stored by eeseg_st_sc1 (write-through) and is
+// loaded by eeseg_ld_sc1 (bypasses this CU's L1); every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets,
+// ONE lane adds the block's arrival (agent-scope atomic) and polls the counter with sc1 loads, the workgroup meets again.
+// No release / acquire fence: a release writes back the whole XCD L2 and, with the acquire, cost 13-17 us per barrier
+// here against 3-6 us for this form (stamps, round 4).
+// state (EESEG_BARRIER_WORDS unsigned words, 128-byte aligned, zeroed ONCE by the owner): group g's arrival counter is
+// word 32*g, its departure counter word 32*(64+g) (lines of their own, g < 64), word 32*128 the sticky give-up word.
+// The last block of a group to leave zeroes the group's two counters, so no memset node precedes the next launch.
+// The spin is bounded: a grid that is not fully resident ends with the give-up word set and wrong results, not a hang.
+#define EESEG_BARRIER_GROUPS 64
+#define EESEG_BARRIER_WORDS (32 * 2 * EESEG_BARRIER_GROUPS + 32)
+typedef __attribute__((address_space(1))) unsigned eeseg_gu32;
+typedef __attribute__((address_space(1))) float eeseg_gf32;
+__device__ __forceinline__ void eeseg_st_sc1(float* p, float v) {
+    __hip_atomic_store((eeseg_gf32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float eeseg_ld_sc1(const float* p) {
+    return __hip_atomic_load((eeseg_gf32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool eeseg_group_barrier(unsigned* state, unsigned group, unsigned members) {
+    __shared__ int ok_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave: its sc1 stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        eeseg_gu32* arrive = (eeseg_gu32*)state + group * 32u;
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        for (unsigned spins = 0; __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members;) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) {                         // seconds: the grid was not co-resident
+                __hip_atomic_store((eeseg_gu32*)state + 32u * 2u * EESEG_BARRIER_GROUPS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_s != 0;
+    if (threadIdx.x == 0) {
+        eeseg_gu32* depart = (eeseg_gu32*)state + (EESEG_BARRIER_GROUPS + group) * 32u;
+        const unsigned old = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == members - 1) {                               // everybody has left the spin: reset for the next launch
+            __hip_atomic_store((eeseg_gu32*)state + group * 32u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return ok;
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }

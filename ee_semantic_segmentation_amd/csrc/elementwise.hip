@@ -666,6 +666,241 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, int lddy
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Train-mode BatchNorm backward in ONE launch for tensors that fit the register files of the chip (the per-GPU shards
+// of a data-parallel run: 4-8 images of 65 x 65): reduce -> grid barrier -> apply, with the operands of the first pass
+// kept in registers across the barrier, so dy and the conv output are read ONCE (2 streamed reads + 1 write instead of
+// 4 reads + 1 write and three launches).  Grid = one 512-thread block per CU, all resident (eeseg_group_barrier among the
+// row blocks of a channel group: statistics are per channel, so channel groups never wait for each other).
+// Block (cg, rb) owns CHB = 8 chunks of channels (128 B of a row) and a contiguous range of `rpb` rows; thread =
+// (chunk tx, row lane rl): rows rb*rpb + rl + 64k.  The first UR rows of a thread stay in registers, later ones (larger
+// tensors) are read again after the barrier (L2 / Infinity Cache hits at these sizes).
+// Summation order (fixed, run to run identical): thread over k ascending -> the 64 row lanes of a block in NSEG = 4 (bf16) /
+// 8 (fp32) ascending segments, the segments ascending -> the row blocks of a channel group likewise.
+struct BnCoopP {
+    const void* dy; const void* y; const void* x; void* dx; void* dres;
+    int lddy, ldy, ldx, lddx, lddres;
+    const float* mean_invstd; const float* gamma; const float* scale_shift;
+    float* sums; float* sums_copy; float* partials; unsigned* state;
+    long long rows, rpb;
+    int C, relu, ncg, nrb;
+    float inv_count;
+};
+
+#ifdef EESEG_COOP_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) of blocks 0 and gridDim-1 behind the partials, nothing reads them
+#define COOP_STAMP(i) if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+    reinterpret_cast<unsigned long long*>(p.partials + 256 * 2 * 64)[(blockIdx.x ? 8 : 0) + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define COOP_STAMP(i)
+#endif
+
+template <typename T, int UR>
+__global__ __launch_bounds__(512) void bn_bwd_coop_kernel(BnCoopP p) {
+    COOP_STAMP(0);
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int CHB = 8 * EPC;                  // channels per block
+    constexpr int NSEG = 512 / (2 * CHB);         // segments of the cross-block sum
+    __shared__ float sred[512][2 * EPC + 1];
+    __shared__ float sseg[NSEG][2 * CHB];
+    __shared__ float stot[2 * CHB];
+    const int tid = threadIdx.x, tx = tid & 7, rl = tid >> 3;
+    const int cgp = blockIdx.x % p.ncg, rb = blockIdx.x / p.ncg;
+    const int c0 = cgp * CHB + tx * EPC;
+    const int C = p.C, relu = p.relu;
+    const T* dy = reinterpret_cast<const T*>(p.dy);
+    const T* xin = reinterpret_cast<const T*>(p.x);
+    const T* yin = reinterpret_cast<const T*>(p.y);
+    const unsigned char* bmask = reinterpret_cast<const unsigned char*>(p.y);
+    const long long r_begin = (long long)rb * p.rpb;
+    const long long r_end = r_begin + p.rpb < p.rows ? r_begin + p.rpb : p.rows;
+
+    float mu[EPC], is[EPC], msc[EPC], msh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        mu[e] = p.mean_invstd[c0 + e];
+        is[e] = p.mean_invstd[C + c0 + e];
+        msc[e] = relu == 2 ? p.scale_shift[c0 + e] : 0.f;
+        msh[e] = relu == 2 ? p.scale_shift[C + c0 + e] : 0.f;
+    }
+    float acc0[EPC], acc1[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+
+    // masked gradient of one row chunk (the ReLU mask applied, rounded back to T: exact) and the sums it feeds
+    auto row_terms = [&](long long r, Vec<T>& g, const Vec<T>& xv) {
+        Vec<T> yv;
+        unsigned mb = 0u;
+        if (relu == 1) yv = ld16(yin + r * p.ldy + c0);
+        if (relu == 3) mb = bmask[r * p.ldy + c0 / EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float gf = to_f32(g.e[e]);
+            const float xf = to_f32(xv.e[e]);
+            if (relu == 1 && !(to_f32(yv.e[e]) > 0.f)) gf = 0.f;
+            if (relu == 3 && !((mb >> e) & 1u)) gf = 0.f;
+            if (relu == 2 && !(xf * msc[e] + msh[e] > 0.f)) gf = 0.f;
+            g.e[e] = from_f32<T>(gf);
+            acc0[e] += gf;
+            acc1[e] += gf * ((xf - mu[e]) * is[e]);
+        }
+    };
+
+    // ---- pass 1: every load of the cached rows in flight before the first is consumed ----
+    Vec<T> gm[UR], xc[UR];
+    const long long r0 = r_begin + rl;
+    {
+        // per-thread row-0 pointers + a block-uniform step per cached row: no per-row 64-bit address lives in registers
+        const T* dy_t = dy + r0 * p.lddy + c0;
+        const T* x_t = xin + r0 * p.ldx + c0;
+        const long long sdy = 64ll * p.lddy, sx = 64ll * p.ldx;
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            if (r0 + 64ll * k < r_end) {
+                gm[k] = ld16(dy_t + k * sdy);
+                xc[k] = ld16(x_t + k * sx);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    COOP_STAMP(1);
+#pragma unroll
+    for (int k = 0; k < UR; ++k) {
+        const long long r = r0 + 64ll * k;
+        if (r < r_end) row_terms(r, gm[k], xc[k]);
+    }
+    COOP_STAMP(2);
+    for (long long rq = r0 + 64ll * UR; rq < r_end; rq += 2 * 64) {       // rows beyond the register cache, 2 rows of loads in flight
+        Vec<T> g[2], xv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r < r_end) { g[u] = ld16(dy + r * p.lddy + c0); xv[u] = ld16(xin + r * p.ldx + c0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r < r_end) row_terms(r, g[u], xv[u]);
+        }
+    }
+    // ---- block sums -> partials[block][2][CHB]: every thread folds 64 / NSEG row lanes (all LDS reads issued before
+    //      the adds), then the NSEG segments in order ----
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sred[tid][e] = acc0[e]; sred[tid][EPC + e] = acc1[e]; }
+    __syncthreads();
+    {
+        constexpr int LPS = 64 / NSEG;               // row lanes per segment
+        const int val = tid % (2 * CHB), seg = tid / (2 * CHB);
+        const int k = val / CHB, col = val - k * CHB;
+        const int sx = col / EPC, e = col - sx * EPC;
+        float v[LPS];
+#pragma unroll
+        for (int l = 0; l < LPS; ++l) v[l] = sred[(seg * LPS + l) * 8 + sx][k * EPC + e];
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < LPS; ++l) s += v[l];
+        sseg[seg][val] = s;
+    }
+    __syncthreads();
+    if (tid < 2 * CHB) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) s += sseg[g][tid];
+        eeseg_st_sc1(p.partials + (long long)blockIdx.x * 2 * CHB + tid, s);      // read by other blocks: write-through
+    }
+    COOP_STAMP(3);
+    eeseg_group_barrier(p.state, (unsigned)cgp, (unsigned)p.nrb);      // among the row blocks of this channel group only
+    COOP_STAMP(4);
+    // ---- totals of this block's channel group: NSEG segments of row blocks (8 loads in flight per thread, added in
+    //      order), then the segments in order ----
+    {
+        const int val = tid % (2 * CHB), seg = tid / (2 * CHB);
+        const int b0 = (int)((long long)seg * p.nrb / NSEG), b1 = (int)((long long)(seg + 1) * p.nrb / NSEG);
+        const float* src = p.partials + (long long)cgp * 2 * CHB + val;
+        const long long bs = (long long)p.ncg * 2 * CHB;
+        float s = 0.f;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = eeseg_ld_sc1(src + (b + i) * bs);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; b < b1; ++b) s += eeseg_ld_sc1(src + b * bs);
+        sseg[seg][val] = s;
+    }
+    __syncthreads();
+    if (tid < 2 * CHB) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) s += sseg[g][tid];
+        stot[tid] = s;
+        if (rb == 0) {
+            const int k = tid / CHB, col = tid - k * CHB;
+            p.sums[(long long)k * C + cgp * CHB + col] = s;
+            if (p.sums_copy) p.sums_copy[(long long)k * C + cgp * CHB + col] = s;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: dx = ka*g + kb*(x - mean) + kc (the arithmetic of bn_bwd_apply_kernel), dres = g ----
+    float ka[EPC], kb[EPC], kc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const float ga = p.gamma ? p.gamma[c0 + e] : 1.f;
+        ka[e] = ga * is[e];
+        kb[e] = -ka[e] * is[e] * stot[CHB + tx * EPC + e] * p.inv_count;
+        kc[e] = -ka[e] * stot[tx * EPC + e] * p.inv_count;
+    }
+    COOP_STAMP(5);
+    T* dx = reinterpret_cast<T*>(p.dx);
+    T* dres = reinterpret_cast<T*>(p.dres);
+    auto row_out = [&](long long r, const Vec<T>& g, const Vec<T>& xv) {
+        Vec<T> od;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            od.e[e] = from_f32<T>(ka[e] * to_f32(g.e[e]) + kb[e] * (to_f32(xv.e[e]) - mu[e]) + kc[e]);
+        st16(dx + r * p.lddx + c0, od);
+        if (dres) st16(dres + r * p.lddres + c0, g);
+    };
+#pragma unroll
+    for (int k = 0; k < UR; ++k) {
+        const long long r = r0 + 64ll * k;
+        if (r < r_end) row_out(r, gm[k], xc[k]);
+    }
+    for (long long rq = r0 + 64ll * UR; rq < r_end; rq += 2 * 64) {       // re-read (L2 / Infinity Cache), 2 rows in flight
+        Vec<T> g2[2], xv2[2], yv2[2];
+        unsigned mb2[2] = {0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r < r_end) {
+                g2[u] = ld16(dy + r * p.lddy + c0);
+                xv2[u] = ld16(xin + r * p.ldx + c0);
+                if (relu == 1) yv2[u] = ld16(yin + r * p.ldy + c0);
+                if (relu == 3) mb2[u] = bmask[r * p.ldy + c0 / EPC];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r >= r_end) continue;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float gf = to_f32(g2[u].e[e]);
+                if (relu == 1 && !(to_f32(yv2[u].e[e]) > 0.f)) gf = 0.f;
+                if (relu == 3 && !((mb2[u] >> e) & 1u)) gf = 0.f;
+                // the mask coefficients are read again here (L1) instead of living in 16 registers across the barrier
+                if (relu == 2 && !(to_f32(xv2[u].e[e]) * p.scale_shift[c0 + e] + p.scale_shift[C + c0 + e] > 0.f)) gf = 0.f;
+                g2[u].e[e] = from_f32<T>(gf);
+            }
+            row_out(r, g2[u], xv2[u]);
+        }
+    }
+    COOP_STAMP(6);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* x, T* y, int N, int H, int W, int C, int Ho, int Wo) {
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -1383,6 +1618,74 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
                            (const float*)y, ldy, (const float*)x, ldx, mean_invstd, gamma, sums, inv, (float*)dx, lddx,
                            (float*)dres, lddres, (long long)rows, C, relu, scale_shift, (g_bn_reverse >> 1) & 1, g_bn_nt);
     }
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+// ---- one-launch BatchNorm backward (bn_bwd_coop_kernel) ----
+int g_bn_coop_max_rpt = 36;          // rows per thread beyond which the fused form is not offered (register cache: up to 12 rows)
+
+struct CoopPlan { int ncg, nrb, ur; long long rpb; };
+static bool bn_coop_plan(int64_t rows, int C, int dtype, CoopPlan* pl) {
+    const int epc = 16 / eeseg_dtype_size(dtype), chb = 8 * epc;
+    const int cus = eeseg_get_option(EESEG_OPT_CONV_CUS);          // CUs a launch may count on (lower while collectives hold some)
+    if (rows <= 0 || C <= 0 || C % chb != 0 || C / chb > cus || C / chb > 64) return false;      // 64 = EESEG_BARRIER_GROUPS
+    pl->ncg = C / chb;
+    pl->nrb = cus / pl->ncg;
+    if ((int64_t)pl->nrb * 64 > rows) pl->nrb = (int)((rows + 63) / 64);
+    if (pl->nrb < 1) pl->nrb = 1;
+    pl->rpb = (rows + pl->nrb - 1) / pl->nrb;
+    pl->nrb = (int)((rows + pl->rpb - 1) / pl->rpb);
+    const long long rpt = (pl->rpb + 63) / 64;
+    if (rpt > g_bn_coop_max_rpt) return false;
+    pl->ur = rpt <= 6 ? 6 : (rpt <= 9 ? 9 : 12);
+    return true;
+}
+
+extern "C" int eeseg_bn_bwd_coop_ok(int64_t rows, int C, int dtype) {
+    if (eeseg_dtype_size(dtype) == 0) return 0;
+    CoopPlan pl;
+    return bn_coop_plan(rows, C, dtype, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t eeseg_bn_bwd_coop_workspace(void) { return 256ll * 2 * 64 * (int64_t)sizeof(float) + 256; }    // + 256 B of diagnostic stamps (EESEG_COOP_STAMPS builds)
+
+extern "C" int eeseg_bn_bwd_coop(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                                 const float* mean_invstd, const float* gamma, const float* scale_shift, double count,
+                                 float* sums, float* sums_copy, void* dx, int lddx, void* dres, int lddres, int64_t rows,
+                                 int C, int relu, int dtype, void* workspace, int64_t workspace_bytes,
+                                 void* barrier_state, void* stream) {
+    EESEG_CHECK(dy && x && mean_invstd && sums && dx && rows > 0 && count > 0 && ((relu != 1 && relu != 3) || y) &&
+                    (relu != 2 || scale_shift) && relu >= 0 && relu <= 3, EESEG_ERR_ARG, "bn_bwd_coop: bad argument");
+    EESEG_CHECK(eeseg_dtype_size(dtype) != 0, EESEG_ERR_ARG, "bn_bwd_coop: bad dtype");
+    EESEG_CHECK(relu != 3 || ldy >= C / (16 / eeseg_dtype_size(dtype)), EESEG_ERR_ARG, "bn_bwd_coop: mask row too short");
+    EESEG_CHECK(dx != dy && dres != dy && dx != x, EESEG_ERR_ARG, "bn_bwd_coop: outputs must not alias the inputs");
+    CHECK_ROWS("bn_bwd_coop dy", dy, lddy, C, dtype);
+    CHECK_ROWS("bn_bwd_coop x", x, ldx, C, dtype);
+    CHECK_ROWS("bn_bwd_coop dx", dx, lddx, C, dtype);
+    if (relu == 1) CHECK_ROWS("bn_bwd_coop y", y, ldy, C, dtype);
+    if (dres) CHECK_ROWS("bn_bwd_coop dres", dres, lddres, C, dtype);
+    CoopPlan pl;
+    EESEG_CHECK(bn_coop_plan(rows, C, dtype, &pl), EESEG_ERR_ARG,
+                "bn_bwd_coop: rows=%lld C=%d does not fit the one-launch form (ask eeseg_bn_bwd_coop_ok first)", (long long)rows, C);
+    EESEG_CHECK(workspace && workspace_bytes >= eeseg_bn_bwd_coop_workspace() && barrier_state &&
+                    ((uintptr_t)barrier_state & 127) == 0, EESEG_ERR_ARG, "bn_bwd_coop: workspace / barrier state (128-byte aligned) missing");
+    BnCoopP p;
+    p.dy = dy; p.y = y; p.x = x; p.dx = dx; p.dres = dres;
+    p.lddy = lddy; p.ldy = ldy; p.ldx = ldx; p.lddx = lddx; p.lddres = lddres;
+    p.mean_invstd = mean_invstd; p.gamma = gamma; p.scale_shift = scale_shift;
+    p.sums = sums; p.sums_copy = sums_copy; p.partials = (float*)workspace; p.state = (unsigned*)barrier_state;
+    p.rows = rows; p.rpb = pl.rpb; p.C = C; p.relu = relu; p.ncg = pl.ncg; p.nrb = pl.nrb;
+    p.inv_count = (float)(1.0 / count);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(pl.ncg * pl.nrb);
+#define EESEG_COOP_LAUNCH(T_) \
+    { if (pl.ur == 6) hipLaunchKernelGGL((bn_bwd_coop_kernel<T_, 6>), grid, dim3(512), 0, st, p); \
+      else if (pl.ur == 9) hipLaunchKernelGGL((bn_bwd_coop_kernel<T_, 9>), grid, dim3(512), 0, st, p); \
+      else hipLaunchKernelGGL((bn_bwd_coop_kernel<T_, 12>), grid, dim3(512), 0, st, p); }
+    if (dtype == EESEG_BF16) EESEG_COOP_LAUNCH(bf16_t)
+    else EESEG_COOP_LAUNCH(float)
+#undef EESEG_COOP_LAUNCH
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

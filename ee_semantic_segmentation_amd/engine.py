@@ -485,7 +485,14 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     x, c, y, mi, count, relu, ss = st[:7]
     frozen = len(st) > 7 and st[7]
     pair = cfg.gview(bn)
-    if synced_sums is not None:
+    dc = None
+    if (synced_sums is None and not frozen and not cfg.sync_active() and not (pair is not None and cfg.accumulate) and
+            K.bn_bwd_coop_ok(c)):
+        # local BatchNorm on a tensor that fits the chip's registers (the 4-8 image shards of a data-parallel run): reduce,
+        # grid barrier and apply in ONE launch, dy and the conv output read once (eeseg_bn_bwd_coop)
+        dc, dres, sums = K.bn_bwd_coop(dy, y if relu else None, c, mi, bn.weight, count, relu, out=pair,
+                                       want_dres=want_dres, dx=dc_out, scale_shift=ss)
+    elif synced_sums is not None:
         # the caller reduced this layer's sums together with its siblings' (head_bwd: one collective for the ASPP branches):
         # `local_sums` = this rank's (already in the arena), `synced_sums` = the group's
         sums = local_sums
@@ -500,7 +507,9 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
     else:
         sums = K.bn_bwd_reduce(dy, y if relu else None, c, mi, relu, out=pair, scale_shift=ss)
     dbeta, dgamma = (None, None) if pair is not None else (sums[0], sums[1])
-    if synced_sums is not None:
+    if dc is not None:
+        pass                                 # the one-launch form has applied the sums already
+    elif synced_sums is not None:
         if pair is None:
             dbeta, dgamma = dbeta.clone(), dgamma.clone()
         sums = synced_sums
@@ -518,8 +527,9 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
             cfg.all_reduce_end(work)
         else:
             _allreduce(cfg, sums)
-    dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
-                              scale_shift=ss, dx=dc_out)        # dc_out: the caller's buffer for the conv-output gradient
+    if dc is None:
+        dc, dres = K.bn_bwd_apply(dy, y if relu else None, c, mi, bn.weight, sums, count, relu, want_dres=want_dres,
+                                  scale_shift=ss, dx=dc_out)    # dc_out: the caller's buffer for the conv-output gradient
     gv = cfg.gview(conv.weight)
     if x_is_col:
         dw = K.conv_wgrad(x, dc, 1, 1)

@@ -553,6 +553,56 @@ def bn_bwd_apply(dy, y, x, mean_invstd, gamma, sums, count, relu, *, want_dres=F
     return dx, dres
 
 
+_coop_state = {}
+COOP_BN_BWD = __import__("os").environ.get("EESEG_COOP_BN_BWD", "1") != "0"      # A/B switch of the one-launch BN backward
+
+
+def coop_state(device):
+    """EESEG_BARRIER_WORDS (4128) zeroed int32 per device: arrival / departure counters of the in-kernel group barriers
+    (the kernels leave them zeroed) + the sticky give-up word (word 4096).  One per device is enough: the kernels that use it all run on the ONE compute
+    stream of a step (eager on torch's current stream, or the capture stream of GraphedTrainStep - never both at once);
+    allocated at the first eager call, i.e. before any capture."""
+    key = str(device)
+    t = _coop_state.get(key)
+    if t is None:
+        t = torch.zeros(4128, dtype=torch.int32, device=device)
+        _coop_state[key] = t
+    return t
+
+
+def coop_timeouts():
+    """Number of barrier states whose give-up word is set (a launch found its grid not co-resident).  Tests assert 0."""
+    return sum(int(t[4096].item() != 0) for t in _coop_state.values())
+
+
+def bn_bwd_coop_ok(x):
+    rows, Cc, _ = rows_ld(x)
+    return COOP_BN_BWD and x.is_cuda and bool(lib().eeseg_bn_bwd_coop_ok(rows, Cc, _dt(x)))
+
+
+def bn_bwd_coop(dy, y, x, mean_invstd, gamma, count, relu, *, out=None, copy=None, want_dres=False, dx=None,
+                scale_shift=None):
+    """bn_bwd_reduce + bn_bwd_apply in one launch (eeseg_bn_bwd_coop) -> (dx, dres, sums [2,C])."""
+    rows, Cc, lddy = rows_ld(dy)
+    _, _, ldx = rows_ld(x)
+    ldy = rows_ld(y)[2] if y is not None else 0
+    sums = out if out is not None else torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    assert sums.is_contiguous() and sums.shape == (2, Cc) and sums.dtype == torch.float32
+    assert copy is None or (copy.is_contiguous() and copy.numel() == 2 * Cc and copy.dtype == torch.float32)
+    if dx is None:
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    lddx = rows_ld(dx)[2]
+    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
+    lddres = rows_ld(dres)[2] if dres is not None else 0
+    ws = workspace(lib().eeseg_bn_bwd_coop_workspace(), x.device)
+    st = coop_state(x.device)
+    check(lib().eeseg_bn_bwd_coop(_p(dy), lddy, _p(y), ldy, _p(x), ldx, _p(mean_invstd), _p(gamma), _p(scale_shift),
+                                  float(count), _p(sums), _p(copy), _p(dx), lddx, _p(dres), lddres, rows, Cc,
+                                  _relu_mode(relu, y, scale_shift), _dt(x), _p(ws), ws.numel(), _p(st), _stream()),
+          "eeseg_bn_bwd_coop")
+    return dx, dres, sums
+
+
 def scale_act_bwd(dy, y, scale, relu, *, want_dres=False):
     rows, Cc, lddy = rows_ld(dy)
     ldy = rows_ld(y)[2] if y is not None else 0

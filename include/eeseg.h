@@ -224,6 +224,22 @@ int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const v
                        const float* mean_invstd, const float* gamma, const float* sums, double count,
                        void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu,
                        const float* scale_shift, int dtype, void* stream);
+/* backward, steps 1 + 2 in ONE launch (round 4; torch BatchNorm2d backward reached through loss.mean().backward(),
+ * train_funcs.py:26) for tensors small enough that a one-block-per-CU grid keeps its rows in registers across a grid-wide
+ * barrier - the per-GPU shards of a data-parallel run (4-8 images of 65 x 65): dy and x are read once instead of twice and
+ * two launches disappear.  Same arguments and results as eeseg_bn_bwd_reduce followed by eeseg_bn_bwd_apply (sums[2][C] =
+ * (dbeta, dgamma) are written too); the cross-block summation order differs from the two-step form (fixed, run-to-run
+ * identical).  eeseg_bn_bwd_coop_ok(rows, C, dtype) says whether the shape fits (C a multiple of 64 bf16 / 32 fp32 channels,
+ * <= 36 rows per thread); workspace >= eeseg_bn_bwd_coop_workspace() bytes; barrier_state: 4128 32-bit words, 128-byte
+ * aligned, ZEROED once by the caller and then owned by the calls on one stream (the kernel leaves it zeroed; word 4096 is a
+ * sticky give-up flag: non-zero = some launch found its grid not co-resident and produced garbage instead of hanging). */
+int eeseg_bn_bwd_coop_ok(int64_t rows, int C, int dtype);
+int64_t eeseg_bn_bwd_coop_workspace(void);
+int eeseg_bn_bwd_coop(const void* dy, int lddy, const void* y, int ldy, const void* x, int ldx,
+                      const float* mean_invstd, const float* gamma, const float* scale_shift, double count,
+                      float* sums, float* sums_copy, void* dx, int lddx, void* dres, int lddres, int64_t rows,
+                      int C, int relu, int dtype, void* workspace, int64_t workspace_bytes, void* barrier_state,
+                      void* stream);
 /* frozen-BN / plain backward of y = act(x*scale+shift): dx = g*scale, dres = g */
 int eeseg_scale_act_bwd(const void* dy, int lddy, const void* y, int ldy, const float* scale,
                         void* dx, int lddx, void* dres, int lddres, int64_t rows, int C, int relu, int dtype,
