@@ -72,6 +72,9 @@ SIGNATURES = {
     "eeseg_bn_apply_relu_mask": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _i, _vp]),
     "eeseg_bn_finalize_apply": (_i, [_vp, _i, _vp, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _i, _i,
                                      _vp]),
+    "eeseg_bn_fwd_fused_ok": (_i, [_i64, _i, _i, _i]),
+    "eeseg_bn_fwd_fused": (_i, [_vp, _i, _vp, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _i,
+                                _i, _vp]),
     "eeseg_channel_stats": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp, _i64, _vp]),
     "eeseg_bn_bwd_reduce": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i64, _vp]),
     "eeseg_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i, _vp, _i, _i64, _i, _i,

@@ -1351,21 +1351,34 @@ constexpr int PW_BM = 128, PW_BN = 256;
 constexpr int PW_ROW = 64;                                   // bytes of K per LDS row (32 bf16 channels)
 constexpr int PW_XS = PW_BM * PW_ROW, PW_WS = PW_BN * PW_ROW;
 constexpr int PW_STAGE = PW_XS + PW_WS;                      // 24 KiB
-constexpr int PW_NST = 3;
+constexpr int PW_NST = 3;                                    // stages of the two-blocks-per-CU form (template NST of the kernel)
 constexpr int PW_SROW = PW_BN * 2 + 16;                      // staged output row (bf16) + pad
 constexpr int PW_EPI = PW_BM * PW_SROW + 4 * 2 * PW_BN * 4;  // staging + [4 waves][2][256] stats
-constexpr int PW_LDS = (PW_EPI > PW_NST * PW_STAGE ? PW_EPI : PW_NST * PW_STAGE) + 16;
+constexpr int pw_lds(int nst) { return (PW_EPI > nst * PW_STAGE ? PW_EPI : nst * PW_STAGE) + 16; }
 
-__global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
+// Round 4: the same kernel for SMALL pixel counts (the 4-8 image shards of a data-parallel run), template parameters:
+//   BMT = 64 / 96 / 128 pixels per tile: 4 x 65 x 65 pixels are 67 tiles of 256 (every one a K-split + fix-up launch on
+//         the 256-tile kernel) but 177 tiles of 96 - one round of whole tiles on 256 CUs, no slabs, no second launch;
+//         the LDS image keeps 128 pixel rows per stage (rows >= BMT are out-of-range loads: zeros, no traffic);
+//   TAPS: the K loop walks R x S filter taps (taps outer, 32-channel chunks inner) with per-row tap-visibility masks -
+//         the 3x3 / dilated layers of a shard; !TAPS = the pointwise form above, no coordinates at all.
+//   NST:  LDS-DMA stages.  3 (72 KiB, two blocks per CU) as above; 6 (144 KiB, ONE block per CU) for launches of at most
+//         one block per CU: a lone block streams its K tiles at (bytes in flight) / (L2 latency) - two 22-KiB tiles in
+//         flight gave ~40 GB/s per block, i.e. 0.55 us per K tile against 0.18 us of MFMA work (3x3 256->256 at 4 images:
+//         46 us); five tiles in flight are what the second block's LDS buys when there is no second block.
+template <int BMT, bool TAPS, int NST>
+__global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) {
     typedef bf16_t T;
     typedef Mma<T>::Frag Frag;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    __shared__ __attribute__((aligned(16))) char smem[PW_LDS];
+    static_assert(BMT == 64 || BMT == 96 || BMT == 128, "pixel tile");
+    constexpr int J = BMT / 32;                              // 32-pixel MFMA column blocks per wave
+    __shared__ __attribute__((aligned(16))) char smem[pw_lds(NST)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;    // cout tiles fastest: the 1..8 blocks that share a pixel tile are neighbours
-    const int m0 = mt * PW_BM, n0 = nt * PW_BN;
+    const int m0 = mt * BMT, n0 = nt * PW_BN;
     EESEG_ACTIVE_EXIT(m0);
     const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
 #ifdef EESEG_PW_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) per block into the conv workspace, nothing reads them
@@ -1375,7 +1388,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
 #endif
     PW_STAMP(0);
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][J];
     {
         // DMA roles: one wave instruction = 16 rows x 64 B (lane -> row lane>>2, chunk slot lane&3).  The first two K
         // tiles are requested before anything else happens in the block (their latency is the longest thing in a tile
@@ -1384,40 +1397,80 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
         uint32_t voffX[2], voffW[4];
+        int baseX[2];                                        // TAPS: byte offset of the tap-(0,0) source pixel of the lane's rows (may be negative)
+        unsigned vmask[2] = {0u, 0u};                        // TAPS: taps that land inside the image, per row
+        const int taps = TAPS ? p.R * p.S : 1;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int r = (wave * 2 + q) * 16 + lrow;
             const int m = m0 + r;
-            voffX[q] = m < p.M ? (uint32_t)(m * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4)) : EESEG_OOB;
+            const bool on = r < BMT && m < p.M;
+            if constexpr (TAPS) {
+                baseX[q] = 0;
+                if (on) {
+                    const int n = m / p.HWout;
+                    const int rem = m - n * p.HWout;
+                    const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+                    const int hb = ho * p.smul + p.off_h, wb = wo * p.smul + p.off_w;
+                    unsigned hm = 0u, wm = 0u;               // separable: tap (r, s) is visible iff r is along h and s along w
+                    for (int rr = 0; rr < p.R; ++rr)
+                        if ((unsigned)(hb + rr * p.tstep_h) < (unsigned)p.Hin) hm |= 1u << rr;
+                    for (int ss = 0; ss < p.S; ++ss)
+                        if ((unsigned)(wb + ss * p.tstep_w) < (unsigned)p.Win) wm |= 1u << ss;
+                    for (int rr = 0; rr < p.R; ++rr)
+                        if ((hm >> rr) & 1u) vmask[q] |= wm << (rr * p.S);
+                    baseX[q] = (((n * p.Hin + hb) * p.Win + wb) * p.Cin) * 2 + ((slot ^ ((r >> 2) & 3)) << 4);
+                }
+                voffX[q] = EESEG_OOB;
+            } else {
+                voffX[q] = on ? (uint32_t)(m * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4)) : EESEG_OOB;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = (wave * 4 + q) * 16 + lrow;
-            voffW[q] = (uint32_t)((n0 + r) * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4));
+            voffW[q] = (uint32_t)((n0 + r) * taps * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4));
         }
-        const int nk = p.Cin / 32;
+        const int nkc = p.Cin / 32;                          // K tiles per tap
+        const int nk = taps * nkc;
+        // block-uniform K iterator of the issue side (K tiles are issued in order 0, 1, 2, ...): tap it_tap, chunk it_ci
+        int it_tap = 0, it_ci = 0;
+        auto set_tap = [&](int tap) {                        // TAPS: the lane's gather offsets of one tap
+            const int r = tap / p.S, s_ = tap - r * p.S;
+            const int dtap = ((r * p.tstep_h) * p.Win + s_ * p.tstep_w) * p.Cin * 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) voffX[q] = ((vmask[q] >> tap) & 1u) ? (uint32_t)(baseX[q] + dtap) : EESEG_OOB;
+        };
+        if constexpr (TAPS) set_tap(0);
         auto issue = [&](int kt, int st) {
             const bool live = kt < nk;                       // past the end: out-of-range loads (zeros, no traffic) keep vmcnt uniform
-            const int soff = kt * PW_ROW;
+            const int soffX = TAPS ? it_ci * PW_ROW : kt * PW_ROW;
+            const int sW = kt * PW_ROW;                      // weights [cout][tap][cin]: K tile kt = tap * nkc + ci starts kt * 64 bytes into a row
             char* sx = smem + st * PW_STAGE;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16,
-                                                         (int)(live ? voffX[q] : EESEG_OOB), soff, 0, 0);
+                                                         (int)(live ? voffX[q] : EESEG_OOB), soffX, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave * 4 + q) * 1024), 16,
-                                                         (int)(live ? voffW[q] : EESEG_OOB), soff, 0, 0);
+                                                         (int)(live ? voffW[q] : EESEG_OOB), sW, 0, 0);
+            if constexpr (TAPS) {                            // advance to K tile kt + 1
+                if (++it_ci == nkc) {
+                    it_ci = 0;
+                    if (++it_tap < taps) set_tap(it_tap);
+                }
+            }
         };
-        issue(0, 0);
-        issue(1, 1);
+        if constexpr (NST > 3) {
+        // One block per CU: nothing else hides this block's LDS fragment reads, so the loop is software-pipelined - the
+        // fragments of K tile t+1 are read (into the other register set) while tile t is multiplied; every stage is in
+        // use (tile t's stage is refilled with tile t+NST as soon as all waves hold its fragments in registers).
+#pragma unroll
+        for (int q = 0; q < NST; ++q) issue(q, q);            // K tiles 0 .. NST-1 (past the end: out-of-range loads)
         PW_STAMP(1);
-        auto ktile = [&](int t, int st, int st2, bool first) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K tile t landed (this wave's pieces)
-            BIG_BARRIER();                                     // ... everybody's; and stage (t-1)%3 has no reader left
-            issue(t + 2, st2);
+        auto rdfr = [&](int st, Frag (&a)[2][2], Frag (&b)[J][2]) {
             const char* sb = smem + st * PW_STAGE;
-            Frag a[2][2], b[4][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const char* r = sb + PW_XS + (wave * 64 + i * 32 + fr) * PW_ROW;
@@ -1425,7 +1478,106 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
                 for (int ks = 0; ks < 2; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < J; ++j) {
+                const char* r = sb + (j * 32 + fr) * PW_ROW;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) b[j][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+            }
+        };
+        Frag fa0[2][2], fb0[J][2], fa1[2][2], fb1[J][2];
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (NST - 1)) : "memory");       // K tile 0 landed
+        BIG_BARRIER();
+        rdfr(0, fa0, fb0);
+        int s_cur = 0;                                         // stage of K tile t
+#ifdef EESEG_PW_DIAG      // diagnostic build: p.tap_inner bit 0 = no MFMAs (after the first tile), bit 1 = no DMA in the loop, bit 2 = no fragment reads
+        const int diag = p.tap_inner;
+#else
+        constexpr int diag = 0;
+#endif
+        // One K tile: 4J MFMAs with the 6 DMA issues of tile t+NST and the 4 + 2J fragment reads of tile t+1 pinned BETWEEN
+        // them (a lone wave per SIMD issues in order: memory instructions ahead of the MFMA block are serial time, between
+        // two MFMAs they ride in the matrix pipe's shadow - diagnostic build: DMA issue 10 us, reads 9 us, MFMAs 14 us of a
+        // 30-us loop when issued one after the other)
+        auto step = [&](int t, const Frag (&ac)[2][2], const Frag (&bc)[J][2], Frag (&an)[2][2], Frag (&bn)[J][2], bool first) {
+            // K tile t+1 landed (tiles t+2 .. t+NST-1 stay in flight) and this wave holds the fragments of tile t
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(6 * (NST - 2)) : "memory");
+            BIG_BARRIER();                                     // ... as does every wave: tile t's stage is free
+            const int kt = t + NST;
+            const bool live = kt < nk;
+            const int soffX = TAPS ? it_ci * PW_ROW : kt * PW_ROW, sW = kt * PW_ROW;
+            char* sx = smem + s_cur * PW_STAGE;
+            const int s_n = s_cur == NST - 1 ? 0 : s_cur + 1;
+            const char* sbn = smem + s_n * PW_STAGE;
+            constexpr int NM = 4 * J, NO = 10 + 2 * J;
+#pragma unroll
+            for (int n = 0; n < NM; ++n) {
+                const int ks = n / (2 * J), j = (n / 2) % J, i = n & 1;
+                if (first || !(diag & 1)) {
+                    if (first && ks == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[i][ks], bc[j][ks], z, 0, 0, 0);
+                    } else {
+                        Mma<T>::run(ac[i][ks], bc[j][ks], acc[i][j]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NO; ++k) {
+                    if (k * NM / NO != n) continue;            // memory op k rides behind MFMA number k * NM / NO
+                    // the fragment reads first: they must have landed at the top of the next step (an LDS read issued behind
+                    // the last MFMA would be exposed latency), the DMA issues last (nobody waits for them for NST-1 steps)
+                    if (k < 4) {
+                        const int fi = k >> 1, fk = k & 1;
+                        if (!(diag & 4))
+                            an[fi][fk] = *reinterpret_cast<const Frag*>(sbn + PW_XS + (wave * 64 + fi * 32 + fr) * PW_ROW + (((fk * 2 + fh) ^ fsw) << 4));
+                    } else if (k < 4 + 2 * J) {
+                        const int fj = (k - 4) >> 1, fk = (k - 4) & 1;
+                        if (!(diag & 4))
+                            bn[fj][fk] = *reinterpret_cast<const Frag*>(sbn + (fj * 32 + fr) * PW_ROW + (((fk * 2 + fh) ^ fsw) << 4));
+                    } else if (k < 6 + 2 * J) {
+                        const int q = k - 4 - 2 * J;
+                        if (!(diag & 2))
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16,
+                                                                     (int)(live ? voffX[q] : EESEG_OOB), soffX, 0, 0);
+                    } else {
+                        const int q = k - 6 - 2 * J;
+                        if (!(diag & 2))
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave * 4 + q) * 1024), 16,
+                                                                     (int)(live ? voffW[q] : EESEG_OOB), sW, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (TAPS) {                              // the issue-side iterator: on to K tile kt + 1
+                if (++it_ci == nkc) {
+                    it_ci = 0;
+                    if (++it_tap < taps) set_tap(it_tap);
+                }
+            }
+            s_cur = s_n;
+        };
+        step(0, fa0, fb0, fa1, fb1, true);
+        for (int t = 1; t < nk; t += 2) {
+            step(t, fa1, fb1, fa0, fb0, false);
+            if (t + 1 < nk) step(t + 1, fa0, fb0, fa1, fb1, false);
+        }
+        } else {
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q) issue(q, q);        // K tiles 0 .. NST-2 (past the end: out-of-range loads)
+        PW_STAMP(1);
+        auto ktile = [&](int t, int st, int st2, bool first) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (NST - 2)) : "memory");   // K tile t landed (this wave's pieces): NST-2 younger tiles stay in flight
+            BIG_BARRIER();                                     // ... everybody's; and stage (t-1) % NST has no reader left
+            issue(t + NST - 1, st2);
+            const char* sb = smem + st * PW_STAGE;
+            Frag a[2][2], b[J][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* r = sb + PW_XS + (wave * 64 + i * 32 + fr) * PW_ROW;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
                 const char* r = sb + (j * 32 + fr) * PW_ROW;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) b[j][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
@@ -1434,7 +1586,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < J; ++j)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (first && ks == 0) {
@@ -1446,12 +1598,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
                     }
             __builtin_amdgcn_s_setprio(0);
         };
-        ktile(0, 0, 2, true);
+        ktile(0, 0, NST - 1, true);
         int st = 1, st2 = 0;
         for (int t = 1; t < nk; ++t) {
             ktile(t, st, st2, false);
-            st = st == PW_NST - 1 ? 0 : st + 1;
-            st2 = st2 == PW_NST - 1 ? 0 : st2 + 1;
+            st = st == NST - 1 ? 0 : st + 1;
+            st2 = st2 == NST - 1 ? 0 : st2 + 1;
+        }
         }
         PW_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing out-of-range DMAs still write (zeros) into LDS
@@ -1474,7 +1627,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
                 if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n0 + cl);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < J; ++j) {
                 const int px = j * 32 + fr;
                 T v[4];
 #pragma unroll
@@ -1487,39 +1640,40 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
     PW_STAMP(4);
 
     // ---- epilogue 2: row-major read back, residual / ReLU, coalesced 16-byte stores, BN partial sums ----
-    const int c = tid & 31, r0 = tid >> 5;                     // 8 rows per pass, 16 passes
+    constexpr int NIT = BMT / 8;                               // 8 rows per pass
+    const int c = tid & 31, r0 = tid >> 5;
     const int cg = n0 + c * 8;
     T* yout = reinterpret_cast<T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.residual);
     const bool post = res != nullptr || p.relu;
-    i32x4 rq[16];
+    i32x4 rq[NIT];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int row = r0 + 8 * it;
         const i32x4 q = *reinterpret_cast<const i32x4*>(stage + row * PW_SROW + c * 16);
         rq[it] = ((row >> 3) & 1) ? i32x4{q[2], q[3], q[0], q[1]} : q;
     }
     if (post) {
-        i32x4 rr[16];
+        i32x4 rr[NIT];
         if (res != nullptr) {                                  // all residual loads in flight before the first use
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 const int m = m0 + r0 + 8 * it;
                 rr[it] = m < p.M ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
             }
             if (p.resmask) {
-                unsigned mb[16];
+                unsigned mb[NIT];
 #pragma unroll
-                for (int it = 0; it < 16; ++it) {
+                for (int it = 0; it < NIT; ++it) {
                     const int m = m0 + r0 + 8 * it;
                     mb[it] = m < p.M ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0u;
                 }
 #pragma unroll
-                for (int it = 0; it < 16; ++it) rr[it] = mask_chunk_bf16(rr[it], mb[it]);
+                for (int it = 0; it < NIT; ++it) rr[it] = mask_chunk_bf16(rr[it], mb[it]);
             }
         }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             union { i32x4 q; T e[8]; } u, ur;
             u.q = rq[it];
             float f[8];
@@ -1543,7 +1697,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
         T* yrow = yout + (size_t)(m0 + r0) * p.ldy + cg;
         const size_t ystep = (size_t)8 * p.ldy;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             if (m0 + r0 + 8 * it < p.M) *reinterpret_cast<i32x4*>(yrow) = rq[it];
             yrow += ystep;
         }
@@ -1554,7 +1708,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(ConvP p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             if (m0 + r0 + 8 * it < p.M) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1862,11 +2016,52 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
 int g_conv_pw_all = 0;        // EESEG_OPT_CONV_PW_ALL: 1 = every eligible pointwise layer on conv_pw_kernel, not only the output-heavy ones
 int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwise layers on the weight-stationary kernel
 
+int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_last_conv_kernel = 0;    // eeseg_last_kernel(0): which kernel the last eeseg_conv_igemm call launched (EESEG_KERNEL_*)
+int g_last_stats_rows = 0;     // eeseg_last_kernel(2): rows of `stats` that call wrote (one per pixel tile of the kernel it chose)
+int g_conv_sm = 1;             // EESEG_OPT_CONV_SMALL_M: layers with <= CUs/2 tiles of 256 x 256 (per-GPU shards) run on the 64/96/128-pixel
+                               // tile kernel (one round of whole tiles) instead of K-split tiles + fix-up on the 256-tile kernel
+int g_conv_sm_deep = 1;        // EESEG_OPT_CONV_SMALL_M_DEEP: launches of <= one block per CU use the six-stage ring
+int g_conv_sm_max_nk = 160;    // EESEG_OPT_CONV_SMALL_M_MAX_K: ... when the K loop has at most this many 32-channel tiles (taps x Cin / 32)
+
+// pixel tile of conv_pw_kernel for a small layer: the tile whose busiest CU has the least work (blocks per CU x (pixels + a
+// per-block fixed cost worth ~40 pixels)); at most two blocks per CU (72 KiB of LDS each)
+int pick_small_bm(long long M, int n_tiles, int cus) {
+    int best = PW_BM;
+    long long best_cost = -1;
+    const int cand[3] = {64, 96, 128};
+    for (int k = 0; k < 3; ++k) {
+        const int bm = cand[k];
+        const long long blocks = ((M + bm - 1) / bm) * n_tiles;
+        if (blocks > 2ll * cus && bm != PW_BM) continue;
+        const long long cost = ((blocks + cus - 1) / cus) * (bm + 40);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
+    }
+    return best;
+}
+
+int launch_pw(ConvP& p, long long M, int bm, bool taps, hipStream_t st) {
+    p.m_tiles = (int)((M + bm - 1) / bm);
+    const dim3 grid((unsigned)(p.m_tiles * p.n_tiles));
+    // at most one block per CU: the deep ring (six stages, 144 KiB) instead of room for a second block
+    const bool deep = g_conv_sm_deep && (long long)p.m_tiles * p.n_tiles <= g_conv_big_cus;
+#define EESEG_LAUNCH_PW(BM_) { \
+        if (taps && deep) hipLaunchKernelGGL((conv_pw_kernel<BM_, true, 6>), grid, dim3(256), 0, st, p); \
+        else if (taps) hipLaunchKernelGGL((conv_pw_kernel<BM_, true, 3>), grid, dim3(256), 0, st, p); \
+        else if (deep) hipLaunchKernelGGL((conv_pw_kernel<BM_, false, 6>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv_pw_kernel<BM_, false, 3>), grid, dim3(256), 0, st, p); }
+    if (bm == 64) EESEG_LAUNCH_PW(64)
+    else if (bm == 96) EESEG_LAUNCH_PW(96)
+    else EESEG_LAUNCH_PW(128)
+#undef EESEG_LAUNCH_PW
+    g_last_conv_kernel = EESEG_KERNEL_CONV_PW;
+    g_last_stats_rows = p.m_tiles;
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
 int g_conv_pw_max_k = 1280;   // EESEG_OPT_CONV_PW_MAX_K: pointwise bf16 layers with Cin <= this use conv_pw_kernel (0 = never)
 
 int g_conv_big_split_min_k = 4;  // EESEG_OPT_CONV_SPLIT_MIN_K: K tiles a K range of a split tail tile holds at least
-int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_conv_big_tail_min = 224;   // a last round with at least this many tiles is left unsplit
 int g_conv_big_merge = 1;        // K-split tail and full rounds in one launch (EESEG_OPT_CONV_TAIL_MERGE)
 int g_conv_big_m16 = 1;          // EESEG_OPT_CONV_MFMA16: 1 (default) = the 256-tile kernel computes with v_mfma_f32_16x16x32_bf16, 0 = 32x32x16 (measured at 32 x 65 x 65: 3-7 % faster on every MFMA-bound layer, scripts/m16_bench.py)
@@ -1962,6 +2157,7 @@ extern int g_last_wgrad_kernel;   // conv_wgrad.hip
 extern "C" int eeseg_last_kernel(int which) {
     if (which == 0) return g_last_conv_kernel;
     if (which == 1) return g_last_wgrad_kernel;
+    if (which == 2) return g_last_stats_rows;
     return EESEG_ERR_ARG;
 }
 
@@ -2046,6 +2242,18 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_pws = value;
         return EESEG_OK;
     }
+    if (key == EESEG_OPT_CONV_SMALL_M && (value == 0 || value == 1)) {
+        g_conv_sm = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_SMALL_M_DEEP && (value == 0 || value == 1)) {
+        g_conv_sm_deep = value;
+        return EESEG_OK;
+    }
+    if (key == EESEG_OPT_CONV_SMALL_M_MAX_K && value >= 0 && value <= 4096) {
+        g_conv_sm_max_nk = value;
+        return EESEG_OK;
+    }
     eeseg_set_error("set_option: unknown key %d / value %d", key, value);
     return EESEG_ERR_ARG;
 }
@@ -2072,14 +2280,17 @@ extern "C" int eeseg_get_option(int key) {
         case EESEG_OPT_CONV_COUT_GROUP: return g_conv_big_cg;
         case EESEG_OPT_CONV_MFMA16: return g_conv_big_m16;
         case EESEG_OPT_CONV_SWP: return g_conv_big_swp;
+        case EESEG_OPT_CONV_SMALL_M: return g_conv_sm;
+        case EESEG_OPT_CONV_SMALL_M_MAX_K: return g_conv_sm_max_nk;
+        case EESEG_OPT_CONV_SMALL_M_DEEP: return g_conv_sm_deep;
     }
     eeseg_set_error("get_option: unknown key %d", key);
     return EESEG_ERR_ARG;
 }
 
-extern "C" int eeseg_conv_stats_tiles(int N, int Hout, int Wout) {
+extern "C" int eeseg_conv_stats_tiles(int N, int Hout, int Wout) {     // upper bound: the smallest pixel tile any kernel uses is 64
     const long long M = (long long)N * Hout * Wout;
-    return (int)((M + BM - 1) / BM);
+    return (int)((M + 63) / 64);
 }
 
 extern "C" int64_t eeseg_conv_workspace(void) {
@@ -2121,6 +2332,9 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     p.xbytes = (uint32_t)xbytes; p.wbytes = (uint32_t)wbytes;
     const int epc = 16 / es;
     p.tap_inner = g_conv_linear;
+#ifdef EESEG_PW_DIAG
+    p.tap_inner = getenv("EESEG_PW_DIAG") ? atoi(getenv("EESEG_PW_DIAG")) : 0;
+#endif
     p.n_tiles = 0; p.tile_begin = 0; p.ksplit = 1; p.slabs = nullptr; p.n_split_blocks = 0; p.pointwise = 0;
     p.n_active = a->n_active;
     p.n_gtaps = 0;
@@ -2173,6 +2387,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             if (a->residual) hipLaunchKernelGGL(conv_pws_kernel<true>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
             else hipLaunchKernelGGL(conv_pws_kernel<false>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
             g_last_conv_kernel = EESEG_KERNEL_CONV_PWS;
+            g_last_stats_rows = p.m_tiles;
             EESEG_LAUNCH_CHECK();
             return EESEG_OK;
         }
@@ -2180,19 +2395,28 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
         // contracting layer would be a K-split + fix-up launch; the 128x256 kernel covers the same layer in one launch of
         // whole tiles (measured at 4 x 65 x 65, R101 step: 24.32 -> 23.74 ms; neutral at 8 images)
         const bool small_m = ((M + BIGT - 1) / BIGT) * (a->Cout / BIGT) <= g_conv_big_cus / 2;
-        if (p.pointwise && a->Cin <= g_conv_pw_max_k && a->Cin % 32 == 0 &&
+        const bool sm = small_m && g_conv_sm;
+        if (p.pointwise && a->Cin % 32 == 0 && (a->Cin <= g_conv_pw_max_k || (sm && a->Cin / 32 <= g_conv_sm_max_nk)) &&
             (g_conv_pw_all || a->Cout >= 2 * a->Cin || a->residual || small_m)) {
             p.n_tiles = a->Cout / PW_BN;
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
-            hipLaunchKernelGGL(conv_pw_kernel, dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(256), 0, st, p);
-            g_last_conv_kernel = EESEG_KERNEL_CONV_PW;
-            EESEG_LAUNCH_CHECK();
-            return EESEG_OK;
+            // round 4: at small M the pixel tile is chosen so that one round of whole tiles covers the chip (4 x 65 x 65: 96 pixels)
+            return launch_pw(p, M, sm ? pick_small_bm(M, p.n_tiles, g_conv_big_cus) : PW_BM, false, st);
+        }
+        // round 4: the 3x3 / dilated layers of a shard on the same kernel with a tap loop - one launch of whole tiles where the
+        // 256-tile kernel would run EVERY tile as K ranges + a fix-up launch (4 x 65 x 65, 3x3 256->256: 56 -> see DESIGN.md)
+        if (sm && !p.pointwise && a->n_taps == 0 && a->Cin % 32 == 0 && a->R * a->S * (a->Cin / 32) <= g_conv_sm_max_nk) {
+            p.n_tiles = a->Cout / PW_BN;
+#ifdef EESEG_PW_STAMPS
+            p.slabs = reinterpret_cast<float*>(a->workspace);
+#endif
+            return launch_pw(p, M, pick_small_bm(M, p.n_tiles, g_conv_big_cus), true, st);
         }
         p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
         g_last_conv_kernel = EESEG_KERNEL_CONV_BIG;
+        g_last_stats_rows = p.m_tiles;
         return launch_big(p, M, st, a->workspace, a->workspace_bytes);
     }
     // 128x64 tiles for thin outputs, and whenever the 128x128 grid would fill less than ~85 % of the
@@ -2201,6 +2425,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
     const bool narrow = a->Cout <= g_conv_narrow_max || (g_conv_auto_narrow && wide_blocks < 448 && a->Cout > 64);
     p.n_tiles = narrow ? (a->Cout + 63) / 64 : (a->Cout + 127) / 128;
     g_last_conv_kernel = narrow ? EESEG_KERNEL_CONV_IGEMM_64 : EESEG_KERNEL_CONV_IGEMM_128;
+    g_last_stats_rows = p.m_tiles;
     if (a->dtype == EESEG_BF16) return narrow ? launch<bf16_t, 64>(p, st) : launch<bf16_t, 128>(p, st);
     return narrow ? launch<float, 64>(p, st) : launch<float, 128>(p, st);
 }

@@ -687,6 +687,139 @@ struct BnCoopP {
     float inv_count;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Train-mode BatchNorm FORWARD behind a conv in ONE launch for small tensors (per-GPU shards): every block reduces the
+// conv-epilogue partial sums of ITS 64 / 32 channels itself (tiles x 2 x CHB floats out of L2: 45-90 KB per block at 4-8
+// images), finalizes them and applies scale / shift (+ residual, ReLU, byte mask) to its rows - bn_reduce_finalize +
+// bn_apply without the launch in between and without a barrier (the reduction is redundant per row block, not shared).
+// Block / thread mapping as bn_bwd_coop_kernel.  The sums are taken in EXACTLY the order of bn_reduce_finalize_kernel
+// (64 tile lanes of fp32 partial sums, then doubles: ((d0+d1)+(d2+d3)) per group of four lanes, the 16 groups in order),
+// the coefficients by its arithmetic, the apply pass by bn_apply_kernel's expression: bit-identical results.
+struct BnFwdP {
+    const void* x; const void* res; void* y; unsigned char* mask;
+    int ldx, ldres, ldy;
+    const float* partials; int tiles;
+    double count; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* mean_invstd; float* scale_shift;
+    long long rows, rpb;
+    int C, relu, ncg, nrb;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void bn_fwd_fused_kernel(BnFwdP p) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int CHB = 8 * EPC;                  // channels per block
+    constexpr int NV = 2 * CHB;                   // (sum, sum of squares) x channels
+    constexpr int NQ = 512 / NV;                  // thread groups over the 64 tile lanes (4 bf16 / 8 fp32)
+    constexpr int LPQ = 64 / NQ;                  // tile lanes per thread (16 / 8): whole groups of four
+    __shared__ double dsum[16][NV];
+    __shared__ float s_sc[CHB], s_sh[CHB];
+    const int tid = threadIdx.x;
+    const int cgp = blockIdx.x % p.ncg, rb = blockIdx.x / p.ncg;
+    const int C = p.C;
+    {
+        const int val = tid % NV, q = tid / NV;
+        const int k = val / CHB, ch = cgp * CHB + (val - k * CHB);
+        const float* src = p.partials + (long long)k * C + ch;
+        const long long ts = 2ll * C;             // floats between consecutive tiles
+        constexpr int NT = 5;                     // partial rows per tile lane, at most (tiles <= 320)
+        float v[LPQ][NT];
+#pragma unroll
+        for (int l = 0; l < LPQ; ++l)             // ALL loads of the thread in flight at once (80 bf16 / 40 fp32): this phase is
+#pragma unroll                                    // L2 latency, a dependent chain per tile lane made it 10 us
+            for (int i = 0; i < NT; ++i) {
+                const int t = q * LPQ + l + 64 * i;
+                v[l][i] = t < p.tiles ? src[t * ts] : 0.f;           // + 0.f leaves the sum's bits alone
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < LPQ / 4; ++g) {       // one group of four tile lanes = one wave of bn_reduce_finalize_kernel
+            double d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) a += v[g * 4 + u][i];
+                d[u] = (double)a;
+            }
+            dsum[q * (LPQ / 4) + g][val] = (d[0] + d[1]) + (d[2] + d[3]);
+        }
+    }
+    __syncthreads();
+    if (tid < CHB) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { t1 += dsum[i][tid]; t2 += dsum[i][CHB + tid]; }
+        const int c = cgp * CHB + tid;
+        const double mean = (double)(float)t1 / p.count;
+        double var = (double)(float)t2 / p.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)p.eps);
+        const float ga = p.gamma ? p.gamma[c] : 1.f, be = p.beta ? p.beta[c] : 0.f;
+        const float sce = (float)(ga * invstd), she = (float)(be - mean * ga * invstd);
+        s_sc[tid] = sce;
+        s_sh[tid] = she;
+        if (rb == 0) {                            // one block per channel group writes the per-channel outputs
+            if (p.mean_invstd) {
+                p.mean_invstd[c] = (float)mean;
+                p.mean_invstd[C + c] = (float)invstd;
+            }
+            p.scale_shift[c] = sce;
+            p.scale_shift[C + c] = she;
+            if (p.running_mean) {
+                const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                p.running_mean[c] = (float)((1.0 - p.momentum) * p.running_mean[c] + p.momentum * mean);
+                p.running_var[c] = (float)((1.0 - p.momentum) * p.running_var[c] + p.momentum * unbiased);
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 7, rl = tid >> 3;
+    const int c0 = cgp * CHB + tx * EPC;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = s_sc[tx * EPC + e]; sh[e] = s_sh[tx * EPC + e]; }
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* y = reinterpret_cast<T*>(p.y);
+    const int cpr = C / EPC;
+    const long long r_begin = (long long)rb * p.rpb;
+    const long long r_end = r_begin + p.rpb < p.rows ? r_begin + p.rpb : p.rows;
+    constexpr int U = 4;                          // rows of loads in flight per thread
+    for (long long rq = r_begin + rl; rq < r_end; rq += U * 64) {
+        Vec<T> v[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r < r_end) {
+                v[u] = ld16(x + r * p.ldx + c0);
+                if (res) rv[u] = ld16(res + r * p.ldres + c0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = rq + 64ll * u;
+            if (r >= r_end) continue;
+            Vec<T> w;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float f = to_f32(v[u].e[e]) * sc[e] + sh[e];
+                if (res) f += to_f32(rv[u].e[e]);
+                if (p.relu) f = fmaxf(f, 0.f);
+                w.e[e] = from_f32<T>(f);
+            }
+            st16(y + r * p.ldy + c0, w);
+            if (p.mask) {
+                unsigned m = 0u;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m |= (to_f32(w.e[e]) > 0.f ? 1u : 0u) << e;
+                p.mask[r * cpr + c0 / EPC] = (unsigned char)m;
+            }
+        }
+    }
+}
+
 #ifdef EESEG_COOP_STAMPS      // diagnostic build: wall-clock stamps (100 MHz) of blocks 0 and gridDim-1 behind the partials, nothing reads them
 #define COOP_STAMP(i) if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
     reinterpret_cast<unsigned long long*>(p.partials + 256 * 2 * 64)[(blockIdx.x ? 8 : 0) + (i)] = __builtin_amdgcn_s_memrealtime()
@@ -1686,6 +1819,52 @@ extern "C" int eeseg_bn_bwd_coop(const void* dy, int lddy, const void* y, int ld
     if (dtype == EESEG_BF16) EESEG_COOP_LAUNCH(bf16_t)
     else EESEG_COOP_LAUNCH(float)
 #undef EESEG_COOP_LAUNCH
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+// ---- one-launch BatchNorm forward behind a conv (bn_fwd_fused_kernel) ----
+int g_bn_fwd_fused_max_tiles = 320;  // conv partial-sum rows beyond which every block reducing them itself costs more than a launch
+
+extern "C" int eeseg_bn_fwd_fused_ok(int64_t rows, int C, int tiles, int dtype) {
+    if (eeseg_dtype_size(dtype) == 0 || tiles <= 0 || tiles > g_bn_fwd_fused_max_tiles) return 0;
+    const int chb = 8 * (16 / eeseg_dtype_size(dtype));
+    const int cus = eeseg_get_option(EESEG_OPT_CONV_CUS);
+    return (rows > 0 && C > 0 && C % chb == 0 && C / chb <= cus) ? 1 : 0;
+}
+
+extern "C" int eeseg_bn_fwd_fused(const void* x, int ldx, const float* partials, int tiles, double count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                  float* mean_invstd, float* scale_shift, const void* residual, int ldres, void* y, int ldy,
+                                  void* relu_mask, int64_t rows, int C, int relu, int dtype, void* stream) {
+    EESEG_CHECK(x && y && partials && scale_shift && count > 0, EESEG_ERR_ARG, "bn_fwd_fused: bad argument");
+    EESEG_CHECK((running_mean == nullptr) == (running_var == nullptr), EESEG_ERR_ARG,
+                "bn_fwd_fused: running_mean/var must both be given or both be NULL");
+    EESEG_CHECK(!relu_mask || relu, EESEG_ERR_ARG, "bn_fwd_fused: the ReLU mask needs relu");
+    EESEG_CHECK(eeseg_bn_fwd_fused_ok(rows, C, tiles, dtype), EESEG_ERR_ARG,
+                "bn_fwd_fused: rows=%lld C=%d tiles=%d does not fit the one-launch form (ask eeseg_bn_fwd_fused_ok first)",
+                (long long)rows, C, tiles);
+    CHECK_ROWS("bn_fwd_fused x", x, ldx, C, dtype);
+    CHECK_ROWS("bn_fwd_fused y", y, ldy, C, dtype);
+    if (residual) CHECK_ROWS("bn_fwd_fused residual", residual, ldres, C, dtype);
+    const int chb = 8 * (16 / eeseg_dtype_size(dtype));
+    const int cus = eeseg_get_option(EESEG_OPT_CONV_CUS);
+    BnFwdP p;
+    p.x = x; p.res = residual; p.y = y; p.mask = (unsigned char*)relu_mask;
+    p.ldx = ldx; p.ldres = ldres; p.ldy = ldy;
+    p.partials = partials; p.tiles = tiles;
+    p.count = count; p.gamma = gamma; p.beta = beta; p.eps = eps; p.momentum = momentum;
+    p.running_mean = running_mean; p.running_var = running_var; p.mean_invstd = mean_invstd; p.scale_shift = scale_shift;
+    p.rows = rows; p.C = C; p.relu = relu;
+    p.ncg = C / chb;
+    p.nrb = 2 * cus / p.ncg;                       // two 512-thread blocks per CU (no barrier: residency is not required)
+    if ((int64_t)p.nrb * 64 > rows) p.nrb = (int)((rows + 63) / 64);
+    if (p.nrb < 1) p.nrb = 1;
+    p.rpb = (rows + p.nrb - 1) / p.nrb;
+    p.nrb = (int)((rows + p.rpb - 1) / p.rpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EESEG_BF16) hipLaunchKernelGGL((bn_fwd_fused_kernel<bf16_t>), dim3(p.ncg * p.nrb), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((bn_fwd_fused_kernel<float>), dim3(p.ncg * p.nrb), dim3(512), 0, st, p);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

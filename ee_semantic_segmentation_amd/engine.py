@@ -419,6 +419,13 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
         y, mask, mi, ss = K.bn_finalize_apply(c, sums, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
                                               residual=residual, relu=relu, out=out, want_mask=want_mask)
         return y, (x, c, mask, mi, count, relu, ss)
+    elif K.bn_fwd_fused_ok(c, part):
+        # small tensors (per-GPU shards): partial reduction, finalize and apply in ONE launch - every block reduces the
+        # partial sums of its own channels itself (eeseg_bn_fwd_fused; bit-identical with the two launches below)
+        bn._pending_batches += 1
+        y, mask, mi, ss = K.bn_fwd_fused(c, part, count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean, bn.running_var,
+                                         residual=residual, relu=relu, out=out, want_mask=residual is not None and relu)
+        return y, (x, c, mask, mi, count, relu, ss)
     elif part.shape[0] > 2048:      # very many tiles (stem): two-level reduction, then finalize
         mi, ss = K.bn_finalize(K.reduce_partials(part), count, bn.weight, bn.bias, bn.eps, mom, bn.running_mean,
                                bn.running_var)

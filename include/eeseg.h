@@ -40,7 +40,10 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_BN_NT = 20 /* bit 0: bn_apply, bit 1: bn_bwd_apply load the tensors that are dead after the pass (conv output / residual; dy / conv output) with a nontemporal hint (default 0) */,
+enum { EESEG_OPT_CONV_SMALL_M_DEEP = 23 /* 1 (default): a launch of the 128x256 kernel with at most one block per CU uses six LDS-DMA stages (144 KiB, five K tiles in flight) instead of three: a lone block streams at bytes-in-flight / L2 latency */,
+       EESEG_OPT_CONV_SMALL_M_MAX_K = 22 /* ... when the K loop has at most this many 32-channel tiles, taps x Cin / 32 (default 160: everything of a ResNet shard but the 2048-wide atrous convs, whose long K loops stay on the 256-tile kernel) */,
+       EESEG_OPT_CONV_SMALL_M = 21 /* 1 (default): bf16 layers with <= CUs / 2 tiles of 256 x 256 (the 4-8 image shards of a data-parallel run) run on the 128x256 kernel with a 64 / 96 / 128 pixel tile chosen so that ONE round of whole tiles covers the chip, 3x3 / dilated layers included (tap loop); 0 = round-3 dispatch (K-split tiles + fix-up launch on the 256-tile kernel) */,
+       EESEG_OPT_BN_NT = 20 /* bit 0: bn_apply, bit 1: bn_bwd_apply load the tensors that are dead after the pass (conv output / residual; dy / conv output) with a nontemporal hint (default 0) */,
        EESEG_OPT_CONV_SWP = 19 /* 256x256 conv kernel, 16x16x32 form: 1 (default) = software-pipelined K loop (the LDS reads of phase p+1 sit between the MFMAs of phase p, the eight waves in lockstep, one barrier per phase); 0 = two wave groups half a phase apart; same bits */,
        EESEG_OPT_BN_BWD_ROWS = 18 /* bn_bwd_apply / scale_act_bwd: rows whose loads a thread keeps in flight (1 = default, 2, 4) */,
        EESEG_OPT_CONV_MFMA16 = 17 /* 256x256 conv kernel: 1 (default) = v_mfma_f32_16x16x32_bf16, 0 = v_mfma_f32_32x32x16_bf16 (same tile, same LDS image, same cycles per FLOP; the chip holds a higher clock on the 16x16 shape: 3-7 % faster) */,
@@ -63,7 +66,8 @@ enum { EESEG_OPT_BN_NT = 20 /* bit 0: bn_apply, bit 1: bn_bwd_apply load the ten
 int eeseg_set_option(int key, int value);
 int eeseg_get_option(int key);   /* current value, or a negative error code */
 /* Which kernel the last eeseg_conv_igemm (which = 0) / eeseg_conv_wgrad (which = 1) call of this process launched - host-side
- * state for measurement code that attributes a timed call to a kernel (bench.py's per-kernel roofline); 0 = none yet. */
+ * state for measurement code that attributes a timed call to a kernel (bench.py's per-kernel roofline); 0 = none yet.
+ * which = 2: the number of `stats` rows the last eeseg_conv_igemm call wrote (depends on the pixel tile of the kernel chosen). */
 enum { EESEG_KERNEL_CONV_IGEMM_128 = 1, EESEG_KERNEL_CONV_IGEMM_64 = 2, EESEG_KERNEL_CONV_BIG = 3 /* 256x256 tile (+ K-split tail, fix-up) */,
        EESEG_KERNEL_CONV_PW = 4 /* 128x256 pointwise */, EESEG_KERNEL_CONV_PWS = 5 /* weight-stationary pointwise */,
        EESEG_KERNEL_WGRAD_128 = 6, EESEG_KERNEL_WGRAD_BIG = 7 };
@@ -124,7 +128,9 @@ typedef struct {
                                      ASPP head (torchvision ASPP: 1x1 + three atrous 3x3, from_deepv3_new.py:13,131) write dx once. */
 } eeseg_conv_args;
 int64_t eeseg_conv_workspace(void);
-int eeseg_conv_stats_tiles(int N, int Hout, int Wout);   /* rows of `stats` */
+/* rows to ALLOCATE for `stats` (upper bound over the kernels: one row per 64 pixels); the rows a call actually wrote =
+ * eeseg_last_kernel(2) right after it (one row per pixel tile of the kernel it chose; the reduction takes exactly those) */
+int eeseg_conv_stats_tiles(int N, int Hout, int Wout);
 int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream);
 
 /* Weight gradient: dw[co][r][s][ci] (+)= sum_{n,ho,wo} dy[n,ho,wo,co]*x[n,hi,wi,ci]
@@ -204,6 +210,16 @@ int eeseg_bn_finalize_apply(const void* x, int ldx, const float* sums, double co
                             float eps, float momentum, float* running_mean, float* running_var, float* mean_invstd,
                             float* scale_shift, const void* residual, int ldres, void* y, int ldy, void* relu_mask,
                             int64_t rows, int C, int relu, int dtype, void* stream);
+/* eeseg_bn_reduce_finalize + eeseg_bn_apply(_relu_mask) in ONE launch (round 4) for small tensors - the per-GPU shards of a
+ * data-parallel run: every block reduces the conv-epilogue partial sums of its own 64 (bf16) / 32 (fp32) channels itself, in
+ * the summation order of eeseg_bn_reduce_finalize, and applies the coefficients to its rows: bit-identical with the two calls
+ * (torch BatchNorm2d forward reached from from_deepv3_new.py:146-151).  eeseg_bn_fwd_fused_ok(rows, C, tiles, dtype): C a
+ * multiple of 64 / 32 and at most 320 partial-sum rows. */
+int eeseg_bn_fwd_fused_ok(int64_t rows, int C, int tiles, int dtype);
+int eeseg_bn_fwd_fused(const void* x, int ldx, const float* partials /*[tiles][2][C]*/, int tiles, double count,
+                       const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, float* mean_invstd, float* scale_shift, const void* residual, int ldres,
+                       void* y, int ldy, void* relu_mask, int64_t rows, int C, int relu, int dtype, void* stream);
 /* per-channel sums of x and x^2 over rows (tensors that did not come out of the
  * conv epilogue, e.g. the pooled ASPP branch): sums[2][C] */
 int eeseg_channel_stats(const void* x, int ldx, int64_t rows, int C, float* sums, int dtype, void* workspace,

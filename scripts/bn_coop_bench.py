@@ -12,17 +12,24 @@ DEV = "cuda"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 
 
-def timed(fn, n=30):
-    for _ in range(5):
+def timed(fn, n=20):
+    """us per call of `fn`, replayed from a HIP graph of n calls (eager launches are host-bound below ~17 us per call)"""
+    for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (3 * n) * 1e3
 
 
 for rows, Cc, mode in [(B * 65 * 65, 256, 2), (B * 65 * 65, 1024, 3), (B * 65 * 65, 512, 2), (B * 65 * 65, 2048, 3),

@@ -27,6 +27,22 @@ def tol(dtype):
     return 1e-4 if dtype == torch.float32 else 1.6e-2
 
 
+@pytest.fixture(autouse=True)
+def _keep_256_tile_tests_on_the_256_tile_kernel(request):
+    """Round 4 sends SMALL layers (<= CUs / 2 tiles of 256 x 256) to the small-M form of the 128x256 kernel
+    (EESEG_OPT_CONV_SMALL_M, tests/test_round4_kernels_gpu.py).  The tests of this file that are ABOUT the 256-tile kernel use
+    small shapes to stay CPU-checkable, so they switch that dispatch off for their duration."""
+    if "256_tile" not in request.node.name or not torch.cuda.is_available():
+        yield
+        return
+    from ee_semantic_segmentation_amd._lib import lib
+    lib().eeseg_set_option(21, 0)
+    try:
+        yield
+    finally:
+        lib().eeseg_set_option(21, 1)
+
+
 def rnd(dtype, *shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     t = torch.randn(*shape, generator=g) * scale
@@ -1157,6 +1173,7 @@ def test_conv_256_tile_mfma_16x16x32(case):
     outs = {}
     try:
         lib().eeseg_set_option(13, 0)                  # keep pointwise layers off the 128x256 kernels for this comparison
+        lib().eeseg_set_option(21, 0)                  # ... and small layers off the round-4 small-M form of that kernel
         for m16 in (0, 1, 2):                          # 2 = 16x16x32 with the software-pipelined K loop (EESEG_OPT_CONV_SWP)
             assert lib().eeseg_set_option(17, int(m16 > 0)) == 0 and lib().eeseg_set_option(19, int(m16 == 2)) == 0
             y, part = K.conv_fwd(xd, wf, 1, pad, dil, want_stats=stats, residual=rd, relu=relu)
@@ -1166,6 +1183,7 @@ def test_conv_256_tile_mfma_16x16x32(case):
         lib().eeseg_set_option(17, 1)
         lib().eeseg_set_option(19, SWP_DEFAULT)
         lib().eeseg_set_option(13, 1280)
+        lib().eeseg_set_option(21, 1)
     for m16, (y, sums) in outs.items():
         close(nchw(y), want, tol(torch.bfloat16), f"mfma16={m16} vs torch")
         if sums is not None:

@@ -153,3 +153,131 @@ def test_grid_barrier_back_to_back_under_uneven_load():
         dx, _, s = K.bn_bwd_coop(dy, None, x, mi, ga, rows, True, scale_shift=ss)
         assert torch.equal(s, s0) and torch.equal(dx, dx0), f"iteration {it}"
     assert K.coop_timeouts() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# conv_pw_kernel<BM, TAPS>: the small-M form of the 128x256 kernel (64 / 96 / 128-pixel tiles, 3x3 / dilated tap loop)
+SMALL_M_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, expected pixel tile
+    (4, 65, 65, 256, 256, 3, 1, 2, 2, 96),       # layer-3 conv2 of a 4-image shard: 177 tiles of 96 px, ragged last tile
+    (4, 65, 65, 256, 256, 3, 1, 1, 1, 96),       # head 3x3
+    (4, 65, 65, 512, 256, 1, 1, 0, 1, 96),       # contracting pointwise
+    (2, 33, 31, 256, 256, 3, 1, 4, 4, 64),       # dilation 4, 32 tiles of 64 px, taps partly outside
+    (1, 20, 23, 128, 512, 3, 1, 1, 1, 64),       # two cout tiles, Cin = 128 (4 K tiles per tap)
+    (2, 65, 65, 64, 256, 3, 2, 1, 1, 64),        # stride 2 forward (gather is linear in the tap): 33 x 33 outputs
+    (8, 65, 65, 256, 256, 3, 1, 2, 2, 0),        # 8 images: 133 tiles of 256 > CUs / 2 -> stays on the 256-tile kernel
+]
+
+
+@pytest.mark.parametrize("case", SMALL_M_CASES, ids=[str(c) for c in SMALL_M_CASES])
+def test_conv_small_m_kernel_vs_torch(case):
+    """forward + BN partial sums, fused scale / shift / residual / ReLU, slice output, data-gradient (plain, accumulating,
+    masked-residual) of the small-M kernel against F.conv2d / its autograd; the dispatch (kernel id, stats rows) as documented;
+    switching the path off (EESEG_OPT_CONV_SMALL_M = 0) gives the round-3 kernels and the same numbers to bf16 rounding."""
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W, Cin, Cout, k, s, p, d, bm = case
+    dtype = torch.bfloat16
+    x = rnd(dtype, N, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(dtype, Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p, dilation=d)
+    gy = rnd(dtype, *y.shape, seed=3)
+    y.backward(gy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    M = N * Ho * Wo
+    xd = nhwc(x.detach()).to(DEV, dtype)
+    wf, wb = K.pack_weight(w.detach().to(DEV), dtype)
+    yd, part = K.conv_fwd(xd, wf, s, p, d, want_stats=True)
+    if bm:
+        assert lib().eeseg_last_kernel(0) == 4 and part.shape[0] == (M + bm - 1) // bm, (lib().eeseg_last_kernel(0), part.shape)
+    else:
+        assert lib().eeseg_last_kernel(0) == 3
+    close(nchw(yd), y, 1.6e-2, "fwd")
+    ys = yd.float().reshape(-1, Cout)
+    sums = K.reduce_partials(part)
+    close(sums[0], ys.sum(0), 1e-4, "stats sum")
+    close(sums[1], (ys * ys).sum(0), 1e-4, "stats sumsq")
+    mi, ss = K.bn_reduce_finalize(part, M, torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV), 1e-5, 0.1, None, None)
+    close(mi[0], ys.mean(0), 1e-3, "mean through bn_reduce_finalize")
+    sc = torch.rand(Cout, generator=torch.Generator().manual_seed(1)) + 0.5
+    sh = torch.randn(Cout, generator=torch.Generator().manual_seed(2))
+    res = rnd(dtype, *y.shape, seed=4)
+    wide = torch.full((N, Ho, Wo, Cout + 256), 7.0, dtype=dtype, device=DEV)
+    K.conv_fwd(xd, wf, s, p, d, scale=sc.to(DEV), shift=sh.to(DEV), residual=nhwc(res).to(DEV, dtype), relu=True,
+               out=wide[..., 128:128 + Cout])
+    want2 = torch.relu(y.detach() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    close(nchw(wide[..., 128:128 + Cout].contiguous()), want2, 1.6e-2, "fused epilogue into a slice")
+    assert bool((wide[..., :128] == 7.0).all()) and bool((wide[..., 128 + Cout:] == 7.0).all())
+    lib().eeseg_set_option(21, 0)
+    try:
+        yd0, part0 = K.conv_fwd(xd, wf, s, p, d, want_stats=True)
+        assert not bm or lib().eeseg_last_kernel(0) != 4 or k == 1
+    finally:
+        lib().eeseg_set_option(21, 1)
+    close(yd, yd0, 8e-3, "small-M kernel vs round-3 dispatch")
+    close(K.reduce_partials(part0), sums, 2e-3, "stats vs round-3 dispatch")
+    if Cin % 256 == 0 and s == 1:
+        gyd = nhwc(gy).to(DEV, dtype)
+        dx = K.conv_dgrad(gyd, wb, (H, W), s, p, d)
+        if bm:
+            assert lib().eeseg_last_kernel(0) == 4
+        close(nchw(dx), x.grad, 1.6e-2, "dgrad")
+        dx2 = K.conv_dgrad(gyd, wb, (H, W), s, p, d, accumulate_into=dx.clone())
+        close(nchw(dx2), 2 * x.grad, 3.2e-2, "dgrad accumulate")
+        t = rnd(dtype, N, H, W, Cin, seed=7).to(DEV, dtype)
+        mask = torch.randint(0, 256, (N * H * W, Cin // 8), dtype=torch.uint8, device=DEV)
+        dx3 = K.conv_dgrad(gyd, wb, (H, W), s, p, d, add=(t, mask))
+        bits = ((mask.unsqueeze(-1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(N, H, W, Cin).float()
+        close(dx3, (dx.float() + t.float() * bits), 1.6e-2, "dgrad + masked residual")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("rows,Cc,tiles", [(4 * 65 * 65, 256, 177), (4 * 65 * 65, 1024, 133), (130, 64, 3), (4 * 129 * 129, 64, 320),
+                                           (8 * 65 * 65, 512, 265)])
+def test_bn_fwd_one_launch_is_bit_identical_with_reduce_finalize_plus_apply(dtype, rows, Cc, tiles):
+    """eeseg_bn_fwd_fused against eeseg_bn_reduce_finalize + eeseg_bn_apply(_relu_mask): same summation order, same arithmetic
+    -> equal bits in y, the ReLU byte mask, mean / invstd, scale / shift and the running statistics (plain, +ReLU, +residual+ReLU+mask,
+    output into a channel slice)."""
+    g = torch.Generator().manual_seed(rows + Cc + tiles)
+    x = (torch.randn(rows, Cc, generator=g) * 1.3 + 0.4).to(DEV, dtype)
+    res = torch.randn(rows, Cc, generator=g).to(DEV, dtype)
+    part = (torch.randn(tiles, 2, Cc, generator=g) * 50).to(DEV).contiguous()       # any partial sums do: the order is what is tested
+    part[:, 1] = part[:, 1].abs() * 4 + 500.0
+    ga = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    be = torch.randn(Cc, generator=g).to(DEV)
+    from ee_semantic_segmentation_amd._lib import lib
+    assert lib().eeseg_bn_fwd_fused_ok(rows, Cc, tiles, 0 if dtype == torch.float32 else 1)
+    for relu, use_res, want_mask in [(False, False, False), (True, False, False), (True, True, True)]:
+        rm1, rv1 = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        mi1, ss1 = K.bn_reduce_finalize(part, rows, ga, be, 1e-5, 0.1, rm1, rv1)
+        r = res if use_res else None
+        if want_mask:
+            y1, m1 = K.bn_apply(x, ss1, residual=r, relu=True, want_mask=True)
+        else:
+            y1, m1 = K.bn_apply(x, ss1, residual=r, relu=relu), None
+        wide = torch.zeros(rows, Cc + 64, dtype=dtype, device=DEV)
+        y2, m2, mi2, ss2 = K.bn_fwd_fused(x, part, rows, ga, be, 1e-5, 0.1, rm2, rv2, residual=r, relu=relu, out=wide[:, 64:],
+                                          want_mask=want_mask)
+        assert torch.equal(mi1, mi2) and torch.equal(ss1, ss2), "coefficients"
+        assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2), "running statistics"
+        assert torch.equal(y1, y2), "output"
+        assert m1 is None or torch.equal(m1, m2), "ReLU byte mask"
+        assert torch.count_nonzero(wide[:, :64]) == 0
+
+
+def test_bn_fwd_one_launch_in_the_layer_function_matches_torch(monkeypatch):
+    """engine.conv_bn_fwd with the (opt-in) fused launch on a shard-sized layer: conv -> BN(train) -> ReLU against torch CPU."""
+    from ee_semantic_segmentation_amd import engine, nn_modules
+    monkeypatch.setattr(K, "FUSED_BN_FWD", True)
+    torch.manual_seed(3)
+    conv = nn_modules.Conv2d(256, 256, 3, padding=2, dilation=2, bias=False).to(DEV)
+    bn = nn_modules.BatchNorm2d(256).to(DEV)
+    cfg = engine.Config()
+    cfg.compute_dtype = torch.bfloat16
+    x = torch.randn(4, 33, 31, 256, device=DEV).to(torch.bfloat16)
+    y, st = engine.conv_bn_fwd(cfg, x, conv, bn, True)
+    ref = F.relu(F.batch_norm(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), conv.weight.detach().bfloat16().float().cpu(),
+                                       padding=2, dilation=2), None, None, bn.weight.detach().cpu(), bn.bias.detach().cpu(),
+                              training=True, eps=bn.eps))
+    close(y.permute(0, 3, 1, 2), ref, 3e-2, "conv -> BN -> ReLU")
