@@ -17,8 +17,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) with
     MFMA peak, plus the 3x3-stack aggregate the north-star target names;
   * `cpu_baseline` (N=1): the oracle (torch CPU fp32 restatement of the reference path) timed
     on a bounded sample of the same architecture on this host's cores;
-  * `secondary` (N=1): BASELINE configs[1] (R50, 2 exits, 21 classes, B=16, bf16) and the fp32
-    parity mode of the headline workload (the mode the 1e-3 logit bar is held in).
+  * `secondary` (N=1): BASELINE configs[1] (R50, 2 exits, 21 classes, B=16, bf16), the fp32 parity mode of the
+    headline workload (the mode the 1e-3 logit bar is held in), the per-GPU shards of the 4- and 8-GPU runs on this
+    one GPU, BASELINE configs[4] (Lovasz, 769 x 769, 8 images) and configs[3] (inference: images/sec + exit histogram).
 """
 import argparse
 import gc
@@ -93,10 +94,15 @@ def _staged_transport(world):
     """REHEARSAL ONLY (--dp-transport gloo): the collectives of an N-rank step staged through host memory over gloo, so the
     multi-process plumbing of this file (rendezvous, shards, barriers, rank-0 line, teardown) can be run with N ranks on
     ONE GPU, where ranks cannot share an RCCL communicator.  Never a measurement: the step cannot be graph-captured."""
+    calls = [0]
+
     def reduce_(t, group):
+        calls[0] += 1
         h = t.detach().cpu()
         dist.all_reduce(h, group=group)
         t.copy_(h)
+
+    reduce_.calls = calls
 
     def gather_(t, group):
         h = t.detach().cpu().contiguous()
@@ -146,12 +152,24 @@ class Run:
         # warm-up: 2 eager steps (allocator, momentum buffers), then the step is captured into a
         # HIP graph and every later call is a replay
         self.reserve_cus = reducer.reserve_cus if reducer.active else 0
+        self.reducer = reducer
         self.runner = GraphedTrainStep(net, crit, opt, reducer, warmup=2,
                                        use_graph=not args.no_graph and net.cfg.collective is None)
         self.net = net
 
     def step(self):
         return self.runner(self.X, self.y)
+
+    def collective_counts(self):
+        """(small 'stat' collectives, gradient buckets) enqueued so far by this process (host-side counters: they advance in
+        eager steps and during a capture, not per graph replay)."""
+        cfg = self.net.cfg
+        grad = self.reducer.launched
+        if cfg.comm is not None:
+            return cfg.comm.stat.calls, cfg.comm.grad.calls
+        if cfg.collective is not None and hasattr(cfg.collective, "calls"):
+            return cfg.collective.calls[0] - grad, grad
+        return 0, 0
 
     def workload(self):
         loss = "CE" if self.loss_name == "ce" else "Lovasz"
@@ -168,7 +186,11 @@ def timed(run, steps, warmup, world, rank, no_graph):
     # the number actually run is reported as config.warmup_steps_run
     warmup_run = max(warmup, 0 if no_graph else 4)
     for i in range(warmup_run):
+        c0 = run.collective_counts()
         l = run.step()
+        if i == 0:                                  # the first step is always eager: its host-side counts are one step's
+            c1 = run.collective_counts()
+            run.stat_collectives_per_step, run.grad_collectives_per_step = c1[0] - c0[0], c1[1] - c0[1]
         if rank == 0:
             torch.cuda.synchronize()
             log(f"warmup {i} done, loss {float(l.item()):.4f}")
@@ -199,12 +221,21 @@ def kernel_events(run, nsteps):
     """Per-kernel HIP-event timing: graph replays cannot be bracketed kernel by kernel, so the same
     step runs eagerly (identical kernels / shapes / launch plans) right after the timed region."""
     from ee_semantic_segmentation_amd import kernels as K
+    from ee_semantic_segmentation_amd.comm import Lane
     run.net.cfg.overlap_wgrad = 0              # per-kernel events need a serial timeline
     K.PROFILE = []
+    Lane.PROFILE = []
     for _ in range(nsteps):
         run.runner._eager(run.X, run.y)
     torch.cuda.synchronize()
     prof, K.PROFILE = K.PROFILE, None
+    joins, Lane.PROFILE = Lane.PROFILE, None
+    # how long the compute stream stood at a lane join, per eager step (ms): the EXPOSED part of the collectives
+    waits = {}
+    for name, e0, e1 in joins:
+        waits[name] = waits.get(name, 0.0) + e0.elapsed_time(e1)
+    run.exposed_ms = {k: v / max(nsteps, 1) for k, v in waits.items()}
+    run.join_count = {k: sum(1 for n, _, _ in joins if n == k) / max(nsteps, 1) for k in waits}
     return prof
 
 
@@ -289,6 +320,10 @@ def main():
     ap.add_argument("--dp-transport", default="rccl", choices=["rccl", "gloo"],
                     help="rccl (default): RCCL through libeeseg.  gloo: REHEARSAL of the N-rank plumbing on one GPU - "
                          "collectives staged through the host, no graph capture; the line is marked, never a measurement")
+    ap.add_argument("--dp-lanes", type=int, default=2, choices=[1, 2],
+                    help="N>1: 2 (default) = gradient buckets and SyncBN collectives on lanes / communicators of their own; "
+                         "1 = EVERY collective on one lane in program order (EESEG_DP_SINGLE_LANE=1: the conservative fallback, "
+                         "comm.py)")
     ap.add_argument("--overlap-wgrad", type=int, default=0, nargs="?", const=1,
                     help="weight-gradient kernels on a side stream: 1 = beside the data-gradient, 2 = after it, beside the "
                          "BatchNorm backward of the layer below (per-kernel timings then overlap)")
@@ -303,6 +338,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.dp_lanes == 1:
+        os.environ["EESEG_DP_SINGLE_LANE"] = "1"
     if os.environ.get("EESEG_REHEARSAL_ONE_GPU") == "1":          # N ranks on the only GPU of a test box (--dp-transport gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -346,10 +383,12 @@ def main():
     if not args.no_kernel_events:              # every rank runs them (the eager steps contain collectives)
         prof_steps = args.roofline_steps
         prof = kernel_events(run, prof_steps)
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [None] * world
+        dist.all_gather_object(every, dt)          # host objects over the gloo rendezvous group
+        rank_ms = sorted(v / args.steps * 1e3 for v in every)
+        dt = max(every)
 
     line = None
     if rank == 0:
@@ -373,6 +412,18 @@ def main():
                            if run.net.cfg.comm is not None else
                            ("REHEARSAL: staged through the host over gloo - not a measurement" if run.net.cfg.collective else None),
                            "reserve_cus": run.reserve_cus,
+                           # what the first multi-GPU record is read with: bucket plan, collectives per
+                           # step, how long the compute stream stood at the lane joins (eager steps after the timed region),
+                           # the per-rank step spread
+                           "dp_lanes": (1 if getattr(run.net.cfg.comm, "single_lane", False) else 2) if run.net.cfg.comm is not None else None,
+                           "defer_wgrad": bool(run.net.cfg.defer_wgrad),
+                           "n_buckets": len(run.reducer.buckets) if run.reducer.active else 0,
+                           "bucket_mib": [round((b - a) * 4 / 2 ** 20, 1) for _, _, a, b in run.reducer.buckets] if run.reducer.active else [],
+                           "syncbn_collectives_per_step": getattr(run, "stat_collectives_per_step", None),
+                           "grad_collectives_per_step": getattr(run, "grad_collectives_per_step", None),
+                           "exposed_allreduce_ms": getattr(run, "exposed_ms", None),
+                           "lane_joins_per_step": getattr(run, "join_count", None),
+                           "step_ms_over_ranks": {"min": rank_ms[0], "median": rank_ms[len(rank_ms) // 2], "max": rank_ms[-1]},
                            "flop_per_image": flop_img, "loss_last_step": loss_val,
                            "splits": list(run.net.split_names)},
                 "roofline": roof}
@@ -430,6 +481,26 @@ def main():
                 del r4
                 gc.collect()
                 torch.cuda.empty_cache()
+            # BASELINE configs[4] shape on this GPU: R101, 3 exits, 19 classes, 769 x 769, 8 images, raw-logit Lovasz (three
+            # segmented radix sorts per step inside the captured graph), SURVEY 8d
+            r5 = Run("resnet101", 2, 19, 769, 8, "bf16", "lovasz", False, 1, 0, dev, args)
+            d5, l5, _ = timed(r5, args.steps, args.warmup, 1, 1, args.no_graph)
+            sec["configs4_lovasz_b8_769"] = {"workload": r5.workload(), "value": 8 * args.steps / d5, "unit": "images/sec",
+                                             "ms_per_step": d5 / args.steps * 1e3, "steps": args.steps,
+                                             "hip_graph": bool(r5.runner.graph is not None),
+                                             "whole_step_tflops": 8 * args.steps / d5 * r5.flop_per_image() / 1e12,
+                                             "loss_last_step": l5}
+            del r5
+            gc.collect()
+            torch.cuda.empty_cache()
+            # BASELINE configs[3]: inference-only, R101, 4 exits, 1024 x 2048, entropy gates on the device: all exits and the
+            # batched truly-progressive form with its exit histogram ("Inference config C4 reports images/sec and
+            # exit histogram"); B = 1 and B = 8
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import infer_bench
+            sec["configs3_infer"] = infer_bench.run(quick=True)
+            gc.collect()
+            torch.cuda.empty_cache()
         except Exception as exc:          # a secondary figure must never cost the headline line
             sec["error"] = repr(exc)
         line["secondary"] = sec

@@ -86,7 +86,7 @@ def train_deepv3(net, num_epochs, kwargs):
     saveat = os.path.join(res_dir, f"{net_id}.pth")
     save_model = kwargs.get("save_model", saveat[:-4] + "final.pth")
     net_res = None
-    for b_size in batch_size if isinstance(batch_size, list) else [batch_size]:
+    for phase, b_size in enumerate(batch_size if isinstance(batch_size, list) else [batch_size]):
         _say(f"<< {net_id} progress update >> B. Size: {b_size}; time: {dttm.datetime.now().strftime('%H:%M:%S')}\n",
              use_file)
         num_workers = kwargs["def_nworkers"](b_size) if "def_nworkers" in kwargs else 0
@@ -116,7 +116,18 @@ def train_deepv3(net, num_epochs, kwargs):
         # parallelism rank r loads the r-th b_size/world slice of every global batch (parallel.ShardSampler; the ragged
         # last batch is dropped there when world > 1, kept like the reference's drop_last=False otherwise)
         world, rank = dp_info(net)
-        sampler = ShardSampler(len(train_set), b_size, world, rank, seed=kwargs.get("seed", 0))
+        # the order follows torch.manual_seed like DataLoader(shuffle=True) does (every rank holds the same initial seed: the
+        # entry points seed before building the network), and every batch-size phase draws its own permutations
+        seed = kwargs.get("seed")
+        if seed is None:
+            seed = torch.initial_seed() % (2 ** 31)
+            if world > 1:                                        # never seeded: the ranks' initial seeds differ - take rank 0's
+                import torch.distributed as dist
+                from .comm import host_group
+                box = [seed]
+                dist.broadcast_object_list(box, src=0, group=host_group(getattr(net.cfg, "group", None)))
+                seed = box[0]
+        sampler = ShardSampler(len(train_set), b_size, world, rank, seed=seed + 7919 * phase)
         train_loader = utils.data.DataLoader(train_set, batch_size=b_size // world, sampler=sampler,
                                              num_workers=num_workers, drop_last=False, prefetch_factor=p_factor,
                                              pin_memory=True)

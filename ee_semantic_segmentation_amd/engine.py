@@ -48,9 +48,11 @@ class Config:
         # SyncBN backward: the weight gradient of layer L is held back and issued right after layer L-1's statistics
         # all-reduce has been launched on the side lane (comm.DataParallelComm.lane_s), so it runs while that latency-bound
         # collective is in flight; in the captured graph the two are parallel branches.  Same mechanism as the gradient
-        # buckets (RCCL through the C ABI on a package-owned stream).  EESEG_DEFER_WGRAD=0: A/B switch (collective on the
-        # compute stream, weight gradient in place).
-        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "1") != "0"
+        # buckets (RCCL through the C ABI on a package-owned stream).  OPT-IN (EESEG_DEFER_WGRAD=1): the only measurement that
+        # exists - the 1-rank rehearsal, where a collective has no latency to hide - has it 0.4 ms slower (27.10 vs 26.67 ms at
+        # 4 images), and no run with more than one rank has executed it; default = collective on the compute stream, weight
+        # gradient in place.
+        self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "0") == "1"
         self._deferred = None
         self.comm = None                     # comm.DataParallelComm: RCCL through libeeseg (parallel.init_data_parallel)
 
@@ -95,7 +97,7 @@ class Config:
         if self.gatherer is not None:
             return self.gatherer(t, self.group)
         if self.comm is not None:
-            return self.comm.stat.all_gather(t.contiguous())
+            return self.comm.stat_all_gather(t.contiguous())
         if t.is_cuda:
             raise self._no_transport(t)
         out = torch.empty((self.dp_world(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
@@ -109,7 +111,7 @@ class Config:
         if self.collective is not None:
             self.collective(t, self.group)
         elif self.comm is not None:
-            self.comm.stat.all_reduce(t)
+            self.comm.stat_all_reduce(t)            # two lanes: on the compute stream; single lane: fork -> lane -> join
         elif t.is_cuda:
             raise self._no_transport(t)
         else:

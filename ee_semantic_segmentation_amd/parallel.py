@@ -8,9 +8,10 @@ buckets that fill in reverse-layer order while backward is still running
 (classifier / deep heads first); a bucket is a plain slice of the gradient arena,
 reduced on the package's own lane stream beside the rest of backward; ``finish()``
 makes the compute stream wait before the optimizer step.  xGMI is point-to-point, so
-buckets are large (default 32 MiB, SURVEY section 5: 25-50 MB) - few, big collectives keep
-every link busy instead of paying per-call latency, while the LAST bucket (it ends with the stem
-and is launched when backward ends, so its all-reduce is exposed) stays small.  BatchNorm statistics (engine.Config.sync_bn) and the CE
+buckets are large (default 32 MiB, SURVEY section 5: 25-50 MB; unmeasured with more than one rank) - few, big
+collectives keep every link busy instead of paying per-call latency, while the LAST bucket (it ends with the stem
+and is launched when backward ends, so its all-reduce is exposed) is capped at ArenaReducer.TAIL_BYTES (4 MiB): the
+bucket before it is closed early.  BatchNorm statistics (engine.Config.sync_bn) and the CE
 valid-pixel count are all-reduced inside the respective layers.  No c10d ``Work`` is
 ever created for a device tensor: comm.py says why.
 """
@@ -152,9 +153,11 @@ def init_data_parallel(net, group=None, sync_bn=True, broadcast=True, transport=
             C_.rccl_version()
         except Exception as exc:                   # noqa: BLE001 - whatever the loader says is the message
             ok, why = 0, repr(exc)
-        if world > 1 and dist.get_backend(group) != "nccl":
+        if world > 1:
+            # over a HOST-ONLY channel whatever the caller's backend (comm.host_group: the group itself for gloo, a gloo
+            # subgroup of it for an NCCL rendezvous group) - an NCCL group would move the flag through device tensors
             flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=C_.host_group(group))
             if int(flag.item()) == 0:
                 raise RuntimeError("RCCL cannot be bound on at least one rank of the job (this rank: "
                                    + (why or "ok") + "); no communicator was created on any rank")
@@ -262,17 +265,38 @@ class ArenaReducer:
             self.reserve_cus = 32 if self.world >= 8 else 0
         if not 0 <= self.reserve_cus <= 192:
             raise ValueError(f"reserve_cus = {self.reserve_cus}: 0 .. 192")
-        self.buckets = []            # (first unit, last unit, start, end)
-        u0, start = 0, 0
-        for u, (a, b) in enumerate(self.arena.unit_ranges):
-            if (b - start) * 4 >= bucket_bytes or u == len(self.arena.unit_ranges) - 1:
-                self.buckets.append((u0, u, start, b))
-                u0, start = u + 1, b
+        self.buckets = self.plan_buckets(self.arena.unit_ranges, bucket_bytes)      # (first unit, last unit, start, end)
         self._done = set()
         self._next = 0
         self._host_div = []
+        self.launched = 0            # buckets launched so far (host-side count: eager steps and captures)
         if self.active:
             self.cfg.on_unit_done = self._unit_done
+
+    TAIL_BYTES = 4 << 20         # the last bucket's all-reduce is exposed (nothing of backward is left to hide it): keep it small
+
+    @classmethod
+    def plan_buckets(cls, unit_ranges, bucket_bytes):
+        """[(first unit, last unit, start, end)] over the arena's units (backward completion order): a bucket closes when
+        it holds >= bucket_bytes; the final bucket is then cut so that what is launched after the LAST unit (the stem) is at
+        most TAIL_BYTES - the units before the cut leave with the bucket before, or as a bucket of their own."""
+        buckets = []
+        u0, start = 0, 0
+        last = len(unit_ranges) - 1
+        for u, (a, b) in enumerate(unit_ranges):
+            if (b - start) * 4 >= bucket_bytes or u == last:
+                buckets.append((u0, u, start, b))
+                u0, start = u + 1, b
+        if buckets:
+            f0, f1, fa, fb = buckets[-1]
+            if (fb - fa) * 4 > cls.TAIL_BYTES and f1 > f0:
+                cut = f1                                   # first unit of the tail: as early as the cap allows
+                while cut - 1 > f0 and (fb - unit_ranges[cut - 1][0]) * 4 <= cls.TAIL_BYTES:
+                    cut -= 1
+                if (fb - unit_ranges[cut][0]) * 4 <= cls.TAIL_BYTES or cut == f1:
+                    mid = unit_ranges[cut][0]
+                    buckets[-1:] = [(f0, cut - 1, fa, mid), (cut, f1, mid, fb)]
+        return buckets
 
     def _unit_done(self, uid):
         self._done.add(uid)
@@ -293,6 +317,7 @@ class ArenaReducer:
             self._plan_cus(256 - self.reserve_cus)
             self._reserved = True
         seg = self.arena.flat[a:b]
+        self.launched += 1
         hook = getattr(self.cfg, "collective", None)
         if hook is not None:                        # test hook (engine.Config.collective): synchronous sum
             hook(seg, self.group)
@@ -330,6 +355,14 @@ class ArenaReducer:
         self._done.clear()
         self._next = 0
         self._host_div = []
+
+    def abort_step(self):
+        """After a step that did not reach finish() (a failed graph capture): forget its buckets and give the conv launch
+        plans the whole chip back."""
+        if self._reserved:
+            self._plan_cus(256)
+            self._reserved = False
+        self.reset()
 
 
 class GraphedTrainStep:
@@ -387,10 +420,17 @@ class GraphedTrainStep:
                     self.loss = self._eager(self.X, self.y)
             except Exception as exc:                # e.g. a collective that cannot be captured
                 import warnings
-                warnings.warn(f"HIP-graph capture of the training step failed ({exc!r}); running eagerly")
                 torch.cuda.synchronize()
                 if self.reducer is not None:
-                    self.reducer.reset()
+                    self.reducer.abort_step()       # bucket bookkeeping and the reduced CU plan of the aborted capture
+                if self.reducer is not None and self.reducer.active and self.reducer.world > 1:
+                    # A per-rank fallback would leave THIS rank eager while the others replay graphs - and the collectives
+                    # enqueued inside the aborted capture never ran here, so the ranks' collective sequences diverge: a hang
+                    # without an error, or wrong sums.  In a multi-rank job a failed capture is fatal.
+                    raise RuntimeError(f"HIP-graph capture of the data-parallel training step failed on rank "
+                                       f"{self.net.cfg.dp_rank()} ({exc!r}); refusing a per-rank eager fallback (the ranks' "
+                                       "collective sequences would diverge) - rerun with use_graph=False on every rank") from exc
+                warnings.warn(f"HIP-graph capture of the training step failed ({exc!r}); running eagerly")
                 # a closure held back by conv_bn_bwd during the aborted capture points into the graph's private pool
                 self.net.cfg.reset_transients()
                 for b, n in zip(self._bns, before):

@@ -43,7 +43,9 @@ def _run(distributed, steps=4):
     net.fused_outputs = True
     comm = init_data_parallel(net, sync_bn=True) if distributed else None
     assert (comm is not None) == distributed and net.cfg.sync_active() == distributed
-    assert not distributed or net.cfg.defer_wgrad          # the side-lane SyncBN backward is the default path
+    # the side-lane SyncBN backward is opt-in (EESEG_DEFER_WGRAD=1); the rehearsal runs both forms
+    assert not distributed or net.cfg.defer_wgrad == (os.environ.get("EESEG_DEFER_WGRAD") == "1")
+    assert comm is None or comm.single_lane == (os.environ.get("EESEG_DP_SINGLE_LANE") == "1")
     net.enable_grad_arena()
     opt = SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     red = ArenaReducer(net, bucket_bytes=32 << 20)
@@ -74,14 +76,24 @@ def _child():
     dist.all_reduce(t)                      # an eager c10d Work for the watchdog to hold
     from ee_semantic_segmentation_amd.comm import rccl_version
     print("RCCL_INIT_OK", rccl_version(), flush=True)
+    got = {}
     try:
-        got = _run(True)
+        # default (two lanes, SyncBN backward on the compute stream), the deferred side-lane form, and the single-lane mode
+        # (every collective of both communicators on ONE lane in program order, comm.py)
+        for name, env in (("default", {}), ("defer", {"EESEG_DEFER_WGRAD": "1"}), ("single_lane", {"EESEG_DP_SINGLE_LANE": "1"})):
+            for k in ("EESEG_DEFER_WGRAD", "EESEG_DP_SINGLE_LANE"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            got[name] = _run(True).tolist()
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
     finally:
         # the captured graph (with its RCCL kernels) must be gone and the device idle before the communicator is torn down
         import gc
         gc.collect()
         torch.cuda.synchronize()
-    print("RESULT " + json.dumps({"base": base.tolist(), "got": got.tolist()}), flush=True)
+    print("RESULT " + json.dumps({"base": base.tolist(), "got": got}), flush=True)
     dist.destroy_process_group()
 
 
@@ -110,13 +122,16 @@ def test_rccl_collectives_in_graph_match_local_run():
     err_lines = "\n".join(l for l in r.stderr.splitlines() if "rror" in l and "frame #" not in l)[:3000]
     assert lines, f"rehearsal child died after RCCL init (rc={r.returncode}):\n{err_lines}\n...\n{r.stderr[-1500:]}"
     res = json.loads(lines[0][len("RESULT "):])
-    base, got = np.array(res["base"]), np.array(res["got"])
-    assert np.all(np.isfinite(got))
-    # same dropout seeds, same data: the first step agrees to fp32 rounding; the SyncBN path sums the
-    # BN partials in a different order than the fused local kernel (1-ulp statistics), so from the second
-    # step on the runs sit inside the chaos band of DESIGN.md section 5
-    assert abs(got[0] - base[0]) < 1e-5 * abs(base[0])
-    assert np.all(np.abs(got - base) < 2e-2 * np.abs(base)), (base.tolist(), got.tolist())
+    base = np.array(res["base"])
+    assert set(res["got"]) == {"default", "defer", "single_lane"}
+    for name, vals in res["got"].items():
+        got = np.array(vals)
+        assert np.all(np.isfinite(got)), name
+        # same dropout seeds, same data: the first step agrees to fp32 rounding; the SyncBN path sums the
+        # BN partials in a different order than the fused local kernel (1-ulp statistics), so from the second
+        # step on the runs sit inside the chaos band of DESIGN.md section 5
+        assert abs(got[0] - base[0]) < 1e-5 * abs(base[0]), name
+        assert np.all(np.abs(got - base) < 2e-2 * np.abs(base)), (name, base.tolist(), got.tolist())
 
 
 if __name__ == "__main__" and "--child" in __import__("sys").argv:
@@ -152,3 +167,12 @@ def test_bench_two_ranks_plumbing_on_one_gpu():
     assert cfg["global_batch"] == 4 and cfg["batch_per_gpu"] == 2 and cfg["parallelism"] == "dp2" and cfg["sync_bn"] is True
     assert "REHEARSAL" in cfg["collectives"] and cfg["hip_graph"] is False
     assert np.isfinite(cfg["loss_last_step"])
+    # the keys the first multi-GPU record is read with: bucket plan, collectives per step, per-rank step spread
+    assert cfg["n_buckets"] >= 1 and len(cfg["bucket_mib"]) == cfg["n_buckets"] and cfg["bucket_mib"][-1] <= 4.0 + 1e-6
+    assert cfg["grad_collectives_per_step"] == cfg["n_buckets"]
+    # R50 / 2 exits: 67 BatchNorm layers, forward + backward, the five ASPP branches of a head sharing one collective each way,
+    # + the CE valid count - anyway more than one per layer and fewer than two
+    assert 67 < cfg["syncbn_collectives_per_step"] <= 2 * 67 + 4, cfg["syncbn_collectives_per_step"]
+    sp = cfg["step_ms_over_ranks"]
+    assert 0 < sp["min"] <= sp["median"] <= sp["max"] and abs(sp["max"] - d["ms_per_step"]) < 1e-6 * sp["max"] + 1e-9
+    assert cfg["defer_wgrad"] is False

@@ -271,3 +271,28 @@ def test_miou_counters_are_summed_over_the_ranks_once_per_evaluation():
     want = (torch.tensor(res[0][1], dtype=torch.float64) + torch.tensor(res[1][1], dtype=torch.float64))
     for _, _, got in res:
         assert torch.equal(torch.tensor(got, dtype=torch.float64), want)
+
+
+def test_bucket_plan_caps_the_exposed_tail_bucket():
+    """ArenaReducer.plan_buckets: buckets close at >= bucket_bytes; the LAST bucket (launched when backward ends, its
+    all-reduce exposed) is cut at a unit boundary so that at most TAIL_BYTES remain behind the cut (the docstring
+    promised a small tail, the loop left up to bucket_bytes)."""
+    from ee_semantic_segmentation_amd.parallel import ArenaReducer
+    M = 1 << 18                                    # floats per MiB
+    sizes = [20, 20, 1, 6, 1, 1, 1]                # MiB per unit, backward completion order (the stem is last and small)
+    ranges, off = [], 0
+    for s_ in sizes:
+        ranges.append((off, off + s_ * M))
+        off += s_ * M
+    plan = ArenaReducer.plan_buckets(ranges, 32 << 20)
+    # [20, 20] closes at 40 MiB; the rest (10 MiB) would be ONE exposed bucket -> cut so that <= 4 MiB stay behind
+    assert plan[0] == (0, 1, 0, 40 * M)
+    assert plan[1][:2] == (2, 3) and plan[2][:2] == (4, 6)
+    assert (plan[2][3] - plan[2][2]) * 4 == 3 << 20 and plan[2][3] == off
+    # buckets tile the arena, in order
+    assert plan[0][2] == 0 and all(a[3] == b[2] for a, b in zip(plan, plan[1:]))
+    # a last unit that alone exceeds the cap cannot be cut: it stays whole, the units before it leave earlier
+    plan2 = ArenaReducer.plan_buckets([(0, 10 * M), (10 * M, 12 * M), (12 * M, 22 * M)], 64 << 20)
+    assert [p[:2] for p in plan2] == [(0, 1), (2, 2)]
+    # one small bucket: untouched
+    assert ArenaReducer.plan_buckets([(0, 100), (100, 300)], 1 << 20) == [(0, 1, 0, 300)]
