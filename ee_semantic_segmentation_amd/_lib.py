@@ -37,7 +37,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p)] + \
                [(n, C.c_int) for n in ("N", "Hin", "Win", "Cin", "Hout", "Wout", "Cout", "R", "S",
                                        "stride", "pad", "dil", "dtype", "accumulate")] + \
-               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong), ("barrier_state", C.c_void_p)]
 
 
 _vp, _i, _i64, _f, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64

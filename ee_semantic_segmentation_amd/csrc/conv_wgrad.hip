@@ -22,6 +22,8 @@ struct WgP {
     int qk, rk, fast_wrap;   // 128x128 kernel: the same for its K step (64 bf16 / 32 f32 pixels); qk + 1 <= Hout
     uint32_t xbytes, dybytes;
     float* slabs;     // 256x256 kernel: per-block fp32 partial tiles (register layout) instead of atomics, or NULL
+    unsigned* bstate; // 256x256 kernel, in-kernel combine (round 4): barrier state; the K splits of a tile meet in the kernel and
+                      // each sums its share of the tile over all splits' slabs (fixed order: reproducible, no atomics, no second launch)
 };
 
 template <typename T>
@@ -222,6 +224,59 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgP p) {
         kt = nx;
     }
 
+    if (p.bstate) {
+        // ---- in-kernel combine (round 4; full 128 x 128 tiles, the whole grid resident at two blocks per CU): as epilogue C
+        // of the 256-tile kernel below - slab in register layout with write-through stores, one barrier per output tile,
+        // split s sums elements [s, s+1) * 4096 / splits over all splits in split order and adds them into dW.  No atomics
+        // (64 KiB of them per block at ~1.3 TB/s chip-wide were 1/3-2/3 of a call at 4-8 images), reproducible.
+        const int tiles = p.co_tiles * p.ci_tiles * taps;
+        const int unit = (int)xcd_remap(blockIdx.x, gridDim.x);
+        const int tl = unit % tiles;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slabs, (uint32_t)((long long)tiles * p.splits * 65536ll));
+        {
+            const uint32_t off = (uint32_t)unit * 65536u + (uint32_t)(wave * 4096 + lane * 4) * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        union { f32x4 f; i32x4 q; } u;
+                        u.f = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(u.q, rs, (int)(off + (uint32_t)(((i * 2 + j) * 4 + g) * 1024)), 0, 16);
+                    }
+        }
+        eeseg_group_barrier(p.bstate, (unsigned)tl, (unsigned)p.splits);
+        const int lo = (int)((long long)split * 4096 / p.splits), hi = (int)((long long)(split + 1) * 4096 / p.splits);
+        for (int idx = lo + tid; idx < hi; idx += 256) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t eo = (uint32_t)tl * 65536u + (uint32_t)idx * 16u;
+            const uint32_t ss = (uint32_t)tiles * 65536u;
+            int s = 0;
+            for (; s + 4 <= p.splits; s += 4) {
+                union { f32x4 f; i32x4 q; } v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u].q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + (uint32_t)(s + u) * ss), 0, 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += v[u].f;
+            }
+            for (; s < p.splits; ++s) {
+                union { f32x4 f; i32x4 q; } v;
+                v.q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + (uint32_t)s * ss), 0, 16);
+                a += v.f;
+            }
+            const int pl = idx & 63, ijg = (idx >> 6) & 15, pw = idx >> 10;           // lane, (i, j, g), wave of the producer
+            const int ai = ijg >> 3, aj = (ijg >> 2) & 1, ag = ijg & 3;
+            const int ci = ci0 + (pw & 1) * 64 + aj * 32 + (pl & 31);
+            const int co = co0 + (pw >> 1) * 64 + ai * 32 + 8 * ag + 4 * (pl >> 5);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* dst = p.dw + ((size_t)(co + k) * taps + tap) * p.Cin + ci;
+                *dst += a[k];
+            }
+        }
+        return;
+    }
     // ---- epilogue: fp32 atomics into dW[co][tap][ci] ---------------------------
     if (!any) return;
     const int fr = lane & 31, fh = lane >> 5;
@@ -714,6 +769,62 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
 #undef EESEG_W16
     if (!lagging) WB_BARRIER();
     WB_WAIT(0);
+    if (p.bstate) {
+        // ---- epilogue C (round 4, default when the whole grid is resident): in-kernel combine.  Every block publishes its
+        // partial tile as a slab with write-through (sc1) 16-byte stores, the K splits of the tile meet (eeseg_group_barrier:
+        // a counter per tile, no fence), then split s sums elements [s, s+1) * 16384 / splits of the tile over ALL splits'
+        // slabs in split order (sc1 loads) and adds them into dW with plain read-modify-writes - it owns them.  Against the
+        // atomics of epilogue B (256 blocks x 256 KiB at ~1.3 TB/s = ~49 us per call whatever the layer): the same bytes as
+        // plain stores + loads, every block reducing its own share in parallel; bitwise reproducible.
+        const int tiles = p.co_tiles * p.ci_tiles * taps;
+        const int tl = unit % tiles;                             // = (tap * ci_tiles + ci_t) * co_tiles + co_t
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.slabs, (uint32_t)((long long)tiles * p.splits * 262144ll));
+        {
+            const uint32_t off = (uint32_t)unit * 262144u + (uint32_t)((wave * 32) * 256 + lane * 4) * 4u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        union { f32x4 f; i32x4 q; } u;
+                        u.f = A.get4(i, j, g);
+                        __builtin_amdgcn_raw_buffer_store_b128(u.q, rs, (int)(off + (uint32_t)(((i * 4 + j) * 4 + g) * 1024)), 0, 16);   // aux 16 = sc1
+                    }
+        }
+        eeseg_group_barrier(p.bstate, (unsigned)tl, (unsigned)p.splits);
+        const int lo = (int)((long long)split * 16384 / p.splits), hi = (int)((long long)(split + 1) * 16384 / p.splits);
+        const int co_t2 = tl % p.co_tiles, ci_t2 = (tl / p.co_tiles) % p.ci_tiles;      // (= co_t, ci_t of this block)
+        for (int idx = lo + tid; idx < hi; idx += 512) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t eo = (uint32_t)tl * 262144u + (uint32_t)idx * 16u;
+            const uint32_t ss = (uint32_t)tiles * 262144u;       // bytes between the same tile's slabs of consecutive splits
+            int s = 0;
+            for (; s + 4 <= p.splits; s += 4) {                   // four loads in flight, added in split order
+                union { f32x4 f; i32x4 q; } v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u].q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + (uint32_t)(s + u) * ss), 0, 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += v[u].f;
+            }
+            for (; s < p.splits; ++s) {
+                union { f32x4 f; i32x4 q; } v;
+                v.q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + (uint32_t)s * ss), 0, 16);
+                a += v.f;
+            }
+            // slab element idx (f32x4 units) -> producing wave, accumulator group, lane -> (4 couts, cin)
+            const int pl = idx & 63, ijg = (idx >> 6) & 31, pw = idx >> 11;
+            const int ai = ijg >> 4, aj = (ijg >> 2) & 3, ag = ijg & 3;
+            const int ci = ci_t2 * 256 + (aj >> 1) * 128 + (pw >> 2) * 64 + (aj & 1) * 32 + wg_sub_ci<M16>(ag, pl);
+            const int co = co_t2 * 256 + ai * 128 + (pw & 3) * 32 + wg_sub_co<M16>(ag, pl);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float* dst = p.dw + ((size_t)(co + k) * taps + tap) * p.Cin + ci;
+                *dst += a[k];
+            }
+        }
+        return;
+    }
     if (p.slabs) {
         // ---- epilogue A (opt-in, reproducible): partial tile -> slab[unit] in register layout (1 KiB per wave store);
         // wgrad_slab_reduce_kernel sums the splits in a fixed order.  Measured 2-5 % slower than the atomics below on the
@@ -801,11 +912,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(WgP p, const flo
 }
 
 int g_wgrad_big = 1;                // eeseg_set_wgrad_big(0|1)
-int g_wgrad_big_min_ktiles = 20;
+int g_wgrad_big_min_ktiles = 8;     // was 20 with the atomics epilogue: with the in-kernel combine short K ranges pay no 256-KiB atomic tile any more (4 images: 21.82 / 21.78 / 21.68 / 21.72 ms per step for 20 / 12 / 8 / 5; 8 images: 33.9 / 34.1 for 12 / 8)
 int g_wgrad_big_blocks = 256;       // EESEG_OPT_WGRAD_BIG_BLOCKS: concurrent blocks the 256x256 wgrad kernel sizes its K split for
 int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this many rounds of them
 int g_wgrad_m16 = 0;                // eeseg_set_wgrad_big(on | 16): 256x256 kernel on v_mfma_f32_16x16x32_bf16
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
+int g_wgrad_coop = 1;               // eeseg_set_wgrad_big(on | 8): 8 (default) = combine the K splits INSIDE the kernel when its whole grid is resident
 int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_target_blocks); 0 = by the cost model below
 
 // Cost model of the 128x128-tile kernel (fitted to scripts/wgrad_sweep.py, MI355X, us): a block takes ~1.0 us per
@@ -813,14 +925,18 @@ int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_
 // and every block ends with one fp32 partial tile of float atomics that run at ~1.3 TB/s chip-wide WHATEVER the layer
 // size - so the block count that is best for a long K (1024) drowns a short one in atomics (50 us per call).
 struct WgPlan { long long splits; double us; };
-static WgPlan plan_wgrad128(long long M, int kp, long long tiles, double tile_bytes, long long max_splits) {
+// max_blocks > 0: the in-kernel combine (all blocks resident, at most max_blocks of them): a block then writes and reads its
+// 64-KiB share with plain write-through stores / loads (~4 TB/s chip-wide) and meets its tile's other splits once (~4 us).
+static WgPlan plan_wgrad128(long long M, int kp, long long tiles, double tile_bytes, long long max_splits, long long max_blocks = 0) {
     const double ksteps = (double)((M + kp - 1) / kp);
-    const double b = tile_bytes / 1.3e6;                       // us of atomic traffic per block
+    const double b = max_blocks > 0 ? 2.0 * tile_bytes / 4.0e6 : tile_bytes / 1.3e6;      // us of combine traffic per block
+    const double fixed = max_blocks > 0 ? 4.0 : 0.0;
+    const long long cap = max_blocks > 0 ? max_blocks : 1536;
     WgPlan best{1, 1e30};
-    for (long long sp = 1; sp <= max_splits && tiles * sp <= 1536; ++sp) {
+    for (long long sp = 1; sp <= max_splits && tiles * sp <= cap; ++sp) {
         const double blocks = (double)(tiles * sp);
         const double per_step = blocks * 0.7 / 256.0 > 1.0 ? blocks * 0.7 / 256.0 : 1.0;
-        const double us = ksteps / (double)sp * per_step + b * blocks;
+        const double us = ksteps / (double)sp * per_step + b * blocks + (sp > 1 ? fixed : 0.0);
         if (us < best.us * 0.98) best = WgPlan{sp, us};
     }
     return best;
@@ -847,6 +963,7 @@ extern "C" int64_t eeseg_wgrad_workspace(void) {
 
 extern "C" int eeseg_set_wgrad_big(int on) {
     g_wgrad_slabs = (on & 4) ? 1 : 0;
+    g_wgrad_coop = (on & 8) ? 1 : 0;
     g_wgrad_m16 = (on & 16) ? 1 : 0;
     on &= 3;
     g_wgrad_big = on > 2 ? 2 : on;
@@ -883,6 +1000,7 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
 
     WgP p;
     p.slabs = nullptr;
+    p.bstate = nullptr;
     p.x = a->x; p.dy = a->dy; p.dw = a->dw;
     p.N = a->N; p.Hin = a->Hin; p.Win = a->Win; p.Cin = a->Cin;
     p.Hout = a->Hout; p.Wout = a->Wout; p.Cout = a->Cout; p.R = a->R; p.S = a->S;
@@ -919,7 +1037,12 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             const WgPlan alt = plan_wgrad128(M, 64, t128, 65536.0, (M + 4 * 64 - 1) / (4 * 64));
             const double blocks = (double)(tiles * splits);
             const double rounds = (double)((tiles * splits + T - 1) / T);
-            const double big_us = rounds * (double)(chunk / 64) * 1.6 + 7.5 + 0.2 * blocks;
+            // combine of the K splits: 256 KiB of atomics per block (~0.2 us each at the chip-wide atomic rate), or - one
+            // resident round, in-kernel combine (epilogue C) - a write-through slab + a share of the reads (~0.07 us) and one barrier
+            extern int eeseg_get_option(int);
+            const bool coop_ok = g_wgrad_coop && splits >= 2 && tiles * splits <= eeseg_get_option(EESEG_OPT_CONV_CUS) &&
+                                 tiles <= EESEG_BARRIER_GROUPS && a->workspace && a->barrier_state;
+            const double big_us = rounds * (double)(chunk / 64) * 1.6 + 7.5 + (coop_ok ? 0.07 * blocks + 4.0 : 0.2 * blocks);
             // the 128-tile estimate is optimistic for few-tile layers (measured at 32 x 65 x 65: 1x1 1024->256 model 111 us, kernel
             // 147 us, against 114 us for the 256-tile kernel; 3x3 256->256 model 230, kernel 257): it has to win clearly
             take_big = big_us <= alt.us * 1.3;
@@ -932,6 +1055,14 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
             const long long need = tiles * (splits + (G > 1 ? G : 0)) * 65536ll * 4;
             p.slabs = (splits >= 2 && g_wgrad_slabs && a->workspace && a->workspace_bytes >= need)
                           ? reinterpret_cast<float*>(a->workspace) : nullptr;
+            // in-kernel combine: every block of the launch resident (one per CU the plans may count on), one barrier group per tile
+            extern int eeseg_get_option(int);
+            if (g_wgrad_coop && splits >= 2 && tiles * splits <= eeseg_get_option(EESEG_OPT_CONV_CUS) && tiles <= EESEG_BARRIER_GROUPS &&
+                a->workspace && a->workspace_bytes >= tiles * splits * 262144ll && a->barrier_state &&
+                ((uintptr_t)a->barrier_state & 127) == 0) {
+                p.slabs = reinterpret_cast<float*>(a->workspace);
+                p.bstate = reinterpret_cast<unsigned*>(a->barrier_state);
+            }
             g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_BIG;
             const bool m16 = g_wgrad_m16 != 0;
             const dim3 grid((unsigned)(tiles * splits));
@@ -946,7 +1077,9 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
                 if (m16) hipLaunchKernelGGL(wgrad_slab_reduce_kernel<true>, g, dim3(256), 0, st, p, src, n, dst);
                 else hipLaunchKernelGGL(wgrad_slab_reduce_kernel<false>, g, dim3(256), 0, st, p, src, n, dst);
             };
-            if (p.slabs && G > 1) {
+            if (p.bstate) {
+                // combined in the kernel: nothing to launch
+            } else if (p.slabs && G > 1) {
                 float* lvl2 = p.slabs + (size_t)tiles * splits * 65536;
                 reduce(dim3((unsigned)(tiles * 8), (unsigned)G), (const float*)p.slabs, (int)splits, lvl2);
                 reduce(dim3((unsigned)(tiles * 8), 1), (const float*)lvl2, (int)G, (float*)nullptr);
@@ -963,10 +1096,26 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     const long long max_splits = (M + 4 * kp - 1) / (4 * kp); // at least 4 K steps per block
     const double tile_bytes = 4.0 * (a->Cout < 128 ? a->Cout : 128) * (a->Cin < 128 ? a->Cin : 128);
     long long splits;
+    bool coop128 = false;
     if (g_wgrad_target_blocks > 0)
         splits = (g_wgrad_target_blocks + tiles - 1) / tiles;
-    else if (a->dtype == EESEG_BF16 && tile_bytes >= 32768.0)
-        splits = plan_wgrad128(M, kp, tiles, tile_bytes, max_splits).splits;
+    else if (a->dtype == EESEG_BF16 && tile_bytes >= 32768.0) {
+        const WgPlan at = plan_wgrad128(M, kp, tiles, tile_bytes, max_splits);
+        splits = at.splits;
+        // in-kernel combine instead of atomics: full tiles, the whole grid resident at two blocks per CU, one barrier group per tile
+        extern int eeseg_get_option(int);
+        const long long cap = 2ll * eeseg_get_option(EESEG_OPT_CONV_CUS);
+        if (g_wgrad_coop && a->Cout % 128 == 0 && a->Cin % 128 == 0 && tiles <= EESEG_BARRIER_GROUPS && tiles <= cap && a->workspace &&
+            a->barrier_state && ((uintptr_t)a->barrier_state & 127) == 0) {
+            const WgPlan cp = plan_wgrad128(M, kp, tiles, tile_bytes, max_splits, cap);
+            // (taken whenever it applies: by the model the two forms are within a few percent of each other at every layer shape of
+            // the workload, and this one gives bitwise reproducible gradients)
+            if (cp.splits >= 2 && a->workspace_bytes >= tiles * cp.splits * 65536ll) {
+                splits = cp.splits;
+                coop128 = true;
+            }
+        }
+    }
     else
         splits = (1024 + tiles - 1) / tiles;                  // narrow (64x64) tiles and fp32: cheap atomics, many blocks
     if (splits > max_splits) splits = max_splits;
@@ -977,6 +1126,10 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
     p.splits = (int)splits; p.chunk = (int)chunk;
     const long long grid = tiles * splits;
     EESEG_CHECK(grid < (1ll << 31), EESEG_ERR_TOO_LARGE, "conv_wgrad: grid too large");
+    if (coop128 && splits >= 2) {
+        p.slabs = reinterpret_cast<float*>(a->workspace);
+        p.bstate = reinterpret_cast<unsigned*>(a->barrier_state);
+    }
     g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_128;
     if (a->dtype == EESEG_BF16)
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);

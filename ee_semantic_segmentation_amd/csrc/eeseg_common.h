@@ -91,10 +91,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // No release / acquire fence: a release writes back the whole XCD L2 and, with the acquire, cost 13-17 us per barrier
 // here against 3-6 us for this form (stamps, round 4).
 // state (EESEG_BARRIER_WORDS unsigned words, 128-byte aligned, zeroed ONCE by the owner): group g's arrival counter is
-// word 32*g, its departure counter word 32*(64+g) (lines of their own, g < 64), word 32*128 the sticky give-up word.
+// word 32*g, its departure counter word 32*(128+g) (lines of their own, g < 128), word 32*256 the sticky give-up word.
 // The last block of a group to leave zeroes the group's two counters, so no memset node precedes the next launch.
 // The spin is bounded: a grid that is not fully resident ends with the give-up word set and wrong results, not a hang.
-#define EESEG_BARRIER_GROUPS 64
+#define EESEG_BARRIER_GROUPS 128
 #define EESEG_BARRIER_WORDS (32 * 2 * EESEG_BARRIER_GROUPS + 32)
 typedef __attribute__((address_space(1))) unsigned eeseg_gu32;
 typedef __attribute__((address_space(1))) float eeseg_gf32;

@@ -1756,13 +1756,14 @@ extern "C" int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int l
 }
 
 // ---- one-launch BatchNorm backward (bn_bwd_coop_kernel) ----
-int g_bn_coop_max_rpt = 36;          // rows per thread beyond which the fused form is not offered (register cache: up to 12 rows)
+int g_bn_coop_max_rpt = 18;          // rows per thread beyond which the fused form is not offered: the register cache holds 12, and with
+                                     // most rows re-read (33 per thread at 32 x 65 x 65 x 256) the fused form measured slower than the two launches
 
 struct CoopPlan { int ncg, nrb, ur; long long rpb; };
 static bool bn_coop_plan(int64_t rows, int C, int dtype, CoopPlan* pl) {
     const int epc = 16 / eeseg_dtype_size(dtype), chb = 8 * epc;
     const int cus = eeseg_get_option(EESEG_OPT_CONV_CUS);          // CUs a launch may count on (lower while collectives hold some)
-    if (rows <= 0 || C <= 0 || C % chb != 0 || C / chb > cus || C / chb > 64) return false;      // 64 = EESEG_BARRIER_GROUPS
+    if (rows <= 0 || C <= 0 || C % chb != 0 || C / chb > cus || C / chb > EESEG_BARRIER_GROUPS) return false;
     pl->ncg = C / chb;
     pl->nrb = cus / pl->ncg;
     if ((int64_t)pl->nrb * 64 > rows) pl->nrb = (int)((rows + 63) / 64);

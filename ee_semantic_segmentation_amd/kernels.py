@@ -139,6 +139,7 @@ def _conv_ws(device):
 
 
 WGRAD_SLABS = False      # True + eeseg_set_wgrad_big(.. | 4): reproducible K-split combine of the 256x256 wgrad kernel
+WGRAD_COOP = __import__("os").environ.get("EESEG_WGRAD_COOP", "1") != "0"      # in-kernel combine of the K splits (round 4; A/B switch)
 
 
 def _wgrad_ws(device):
@@ -336,9 +337,11 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
     a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cin, Ho, Wo, Cout, R, S
     a.stride, a.pad, a.dil, a.dtype, a.accumulate = stride, pad, dil, _dt(x), int(accumulate)
-    if WGRAD_SLABS and a.dtype == BF16 and Cout % 256 == 0 and Cin % 256 == 0:
+    if (WGRAD_SLABS or WGRAD_COOP) and a.dtype == BF16 and Cout % 128 == 0 and Cin % 128 == 0:
         ws = _wgrad_ws(x.device)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        if WGRAD_COOP:
+            a.barrier_state = coop_state(x.device, "wgrad").data_ptr()
     ev = _prof_begin()
     check(lib().eeseg_conv_wgrad(C.byref(a), _stream()), "eeseg_conv_wgrad")
     if ev is not None:
@@ -596,22 +599,23 @@ _coop_state = {}
 COOP_BN_BWD = __import__("os").environ.get("EESEG_COOP_BN_BWD", "1") != "0"      # A/B switch of the one-launch BN backward
 
 
-def coop_state(device):
-    """EESEG_BARRIER_WORDS (4128) zeroed int32 per device: arrival / departure counters of the in-kernel group barriers
-    (the kernels leave them zeroed) + the sticky give-up word (word 4096).  One per device is enough: the kernels that use it all run on the ONE compute
-    stream of a step (eager on torch's current stream, or the capture stream of GraphedTrainStep - never both at once);
-    allocated at the first eager call, i.e. before any capture."""
-    key = str(device)
+def coop_state(device, role="bn"):
+    """EESEG_BARRIER_WORDS (8224) zeroed int32 per device and role: arrival / departure counters of the in-kernel group
+    barriers (the kernels leave them zeroed) + the sticky give-up word (word 8192).  One per (device, kernel family): the
+    kernels of one family all run on ONE stream of a step (the compute stream - eager on torch's current stream, or the capture
+    stream of GraphedTrainStep, never both at once; the weight gradients possibly on the side stream of overlap_wgrad, hence a
+    state of their own); allocated at the first eager call, i.e. before any capture."""
+    key = (str(device), role)
     t = _coop_state.get(key)
     if t is None:
-        t = torch.zeros(4128, dtype=torch.int32, device=device)
+        t = torch.zeros(8224, dtype=torch.int32, device=device)
         _coop_state[key] = t
     return t
 
 
 def coop_timeouts():
     """Number of barrier states whose give-up word is set (a launch found its grid not co-resident).  Tests assert 0."""
-    return sum(int(t[4096].item() != 0) for t in _coop_state.values())
+    return sum(int(t[8192].item() != 0) for t in _coop_state.values())
 
 
 def bn_bwd_coop_ok(x):

@@ -79,14 +79,15 @@ int eeseg_set_ew_grid_cap(int blocks);
 int eeseg_set_wgrad_target_blocks(int blocks);
 /* bf16 weight gradients with Cout % 256 == 0 and Cin % 256 == 0: 1 (default) = 256x256-tile kernel when every block
  * gets at least 20 K tiles (64 pixels each), 2 = always, 0 = never (128x128-tile kernel); +4 = combine the K splits through
- * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics; +16 = the 256x256-tile kernel computes with
+ * the workspace slabs (reproducible, 2-5 % slower) instead of fp32 atomics; +8 (default on) = combine them INSIDE the kernel when
+ * its whole grid is resident and eeseg_wgrad_args.barrier_state is given (reproducible; round 4); +16 = the 256x256-tile kernel computes with
  * v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same results up to fp32 summation order; measured neutral, default off) */
 int eeseg_set_wgrad_big(int on);
 /* K-split sizing of the 256x256 weight-gradient kernel: aim at `blocks` concurrent blocks (default 256 = one per CU) and
  * at most `rounds` rounds of them (default 8).  Fewer blocks = fewer fp32 partial tiles to combine; use with the weight
  * gradient on a side stream so that the other CUs are not idle. */
 int eeseg_set_wgrad_big_grid(int blocks, int rounds);
-/* the 256x256 weight-gradient kernel is used when every block gets at least this many K tiles (default 20) */
+/* the 256x256 weight-gradient kernel is used when every block gets at least this many K tiles (default 8; 20 before the in-kernel combine of round 4) */
 int eeseg_set_wgrad_big_min_ktiles(int n);
 
 /* ---------------------------------------------------------------- conv ----
@@ -143,6 +144,11 @@ typedef struct {
     void* workspace;              /* optional scratch (NULL = none) for eeseg_set_wgrad_big(.. | 4): the 256x256-tile kernel then combines */
     int64_t workspace_bytes;      /* its K splits through plain-store slabs + a fixed-order reduce (bitwise reproducible) instead of fp32
                                      atomics; eeseg_wgrad_workspace() bytes suffice */
+    void* barrier_state;          /* optional (NULL = none; round 4): with `workspace`, lets the 256x256-tile kernel combine its K splits
+                                     INSIDE the launch when its whole grid is resident (one block per CU): slabs published write-through,
+                                     a barrier per output tile, every split sums its share in split order - no atomics (~49 us per call),
+                                     no second launch, bitwise reproducible.  4128+ 32-bit words as eeseg_bn_bwd_coop's (8224: 128 groups),
+                                     128-byte aligned, zeroed ONCE by the caller, owned by the weight-gradient calls of one stream. */
 } eeseg_wgrad_args;
 int64_t eeseg_wgrad_workspace(void);
 int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
@@ -246,8 +252,8 @@ int eeseg_bn_bwd_apply(const void* dy, int lddy, const void* y, int ldy, const v
  * two launches disappear.  Same arguments and results as eeseg_bn_bwd_reduce followed by eeseg_bn_bwd_apply (sums[2][C] =
  * (dbeta, dgamma) are written too); the cross-block summation order differs from the two-step form (fixed, run-to-run
  * identical).  eeseg_bn_bwd_coop_ok(rows, C, dtype) says whether the shape fits (C a multiple of 64 bf16 / 32 fp32 channels,
- * <= 36 rows per thread); workspace >= eeseg_bn_bwd_coop_workspace() bytes; barrier_state: 4128 32-bit words, 128-byte
- * aligned, ZEROED once by the caller and then owned by the calls on one stream (the kernel leaves it zeroed; word 4096 is a
+ * <= 18 rows per thread); workspace >= eeseg_bn_bwd_coop_workspace() bytes; barrier_state: 8224 32-bit words, 128-byte
+ * aligned, ZEROED once by the caller and then owned by the calls on one stream (the kernel leaves it zeroed; word 8192 is a
  * sticky give-up flag: non-zero = some launch found its grid not co-resident and produced garbage instead of hanging). */
 int eeseg_bn_bwd_coop_ok(int64_t rows, int C, int dtype);
 int64_t eeseg_bn_bwd_coop_workspace(void);

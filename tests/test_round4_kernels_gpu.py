@@ -85,10 +85,10 @@ def test_bn_bwd_one_launch_vs_torch(dtype, relu, use_res):
     assert K.coop_timeouts() == 0
 
 
-# rows, C: the BatchNorm tensors of a 4-image (and one 8-image) shard at 513 x 513 - every register-cache tier, the
-# re-read tail (33 800 x 1024: 34 rows per thread, 14 cached), ragged row blocks, one channel group (C = 64)
-SHARD_SHAPES = [(4 * 65 * 65, 256), (4 * 65 * 65, 1024), (4 * 65 * 65, 2048), (4 * 129 * 129, 64), (4 * 129 * 129, 256),
-                (8 * 65 * 65, 1024), (130, 64), (64, 512), (4 * 65 * 65, 512)]
+# rows, C: the BatchNorm tensors of a 4-image (and 8-image) shard at 513 x 513 - every register-cache tier, the re-read tail
+# (16 900 x 1024 and 33 800 x 512: 17 rows per thread, 12 cached), ragged row blocks, one channel group (C = 64)
+SHARD_SHAPES = [(4 * 65 * 65, 256), (4 * 65 * 65, 1024), (4 * 129 * 129, 64), (4 * 129 * 129, 256),
+                (8 * 65 * 65, 512), (130, 64), (64, 512), (4 * 65 * 65, 512)]
 
 
 @pytest.mark.parametrize("rows,Cc", SHARD_SHAPES, ids=[f"{r}x{c}" for r, c in SHARD_SHAPES])
@@ -127,8 +127,9 @@ def test_bn_bwd_one_launch_equals_the_two_launch_form(rows, Cc):
 
 def test_bn_bwd_one_launch_is_not_offered_for_large_or_odd_tensors():
     big = torch.empty(32 * 65 * 65, 1024, dtype=torch.bfloat16, device=DEV)
+    mid = torch.empty(32 * 65 * 65, 256, dtype=torch.bfloat16, device=DEV)      # 33 rows per thread: mostly re-read, measured slower
     odd = torch.empty(1000, 40, dtype=torch.bfloat16, device=DEV)
-    assert not K.bn_bwd_coop_ok(big) and not K.bn_bwd_coop_ok(odd)
+    assert not K.bn_bwd_coop_ok(big) and not K.bn_bwd_coop_ok(mid) and not K.bn_bwd_coop_ok(odd)
 
 
 def test_grid_barrier_back_to_back_under_uneven_load():
@@ -281,3 +282,48 @@ def test_bn_fwd_one_launch_in_the_layer_function_matches_torch(monkeypatch):
                                        padding=2, dilation=2), None, None, bn.weight.detach().cpu(), bn.bias.detach().cpu(),
                               training=True, eps=bn.eps))
     close(y.permute(0, 3, 1, 2), ref, 3e-2, "conv -> BN -> ReLU")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, k, pad, dil
+    (8, 65, 65, 256, 256, 3, 2, 2),        # 9 tiles x 28 splits = 252 blocks: the layer-3 conv2 of the metric's step (at 8 images)
+    (8, 65, 65, 1024, 256, 1, 0, 1),       # 4 tiles x 64 splits
+    (4, 65, 65, 512, 512, 3, 4, 4),        # 36 tiles x 7 splits, ragged K ranges
+    (6, 40, 70, 256, 512, 1, 0, 1),        # Wout > 64 (the FAST iterator), 2 tiles
+], ids=str)
+@pytest.mark.parametrize("big", [2, 0], ids=["256-tile", "128-tile"])
+def test_wgrad_in_kernel_combine_is_reproducible_and_matches_atomics_and_torch(shape, big):
+    """conv_wgrad_big_kernel, epilogue C (eeseg_set_wgrad_big(.. | 8), the default): the K splits of an output tile meet inside
+    the launch and sum their slabs in split order - against torch's weight gradient, against the atomics epilogue (same MFMAs,
+    other summation order of the splits), bit-identical run to run (the atomics are not), accumulate mode, counters left clean."""
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W, Cin, Cout, k, pad, dil = shape
+    dt = torch.bfloat16
+    x = rnd(dt, N, Cin, H, W, seed=1).requires_grad_(False)
+    w = rnd(dt, Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, padding=pad, dilation=dil)
+    gy = rnd(dt, *y.shape, seed=3)
+    y.backward(gy)
+    xd, gyd = nhwc(x).to(DEV, dt), nhwc(gy).to(DEV, dt)
+    try:
+        assert lib().eeseg_set_wgrad_big(big | 8) == 0             # 2 = the 256-tile kernel whatever the cost model says, 0 = never
+        dw1 = K.conv_wgrad(xd, gyd, k, k, 1, pad, dil)
+        assert lib().eeseg_last_kernel(1) == (7 if big else 6)
+        dw2 = K.conv_wgrad(xd, gyd, k, k, 1, pad, dil)
+        tile = 256 if big else 128
+        eligible = (Cout // tile) * (Cin // tile) * k * k <= 128   # one barrier group per output tile (EESEG_BARRIER_GROUPS)
+        if eligible:
+            assert torch.equal(dw1, dw2), "in-kernel combine: fixed summation order, identical bits run to run"
+            acc = dw1.clone()
+            K.conv_wgrad(xd, gyd, k, k, 1, pad, dil, out=acc, accumulate=True)
+            assert torch.equal(acc, dw1 + dw1)                     # owner adds into what is there
+        assert lib().eeseg_set_wgrad_big(big) == 0                 # atomics
+        dwa = K.conv_wgrad(xd, gyd, k, k, 1, pad, dil)
+    finally:
+        lib().eeseg_set_wgrad_big(1 | 8)
+    close(dw1.permute(0, 3, 1, 2), w.grad, 4e-3, "vs torch")
+    close(dw1, dwa, 1e-5, "vs the atomics epilogue")
+    st = K.coop_state(xd.device, "wgrad")
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(st).item() == 0
