@@ -114,7 +114,8 @@ SIGNATURES = {
     "eeseg_entropy_gate_workspace": (_i64, [_i, _i, _i]),
     "eeseg_entropy_gate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp]),
     "eeseg_lovasz_workspace": (_i64, [_i64, _i]),
-    "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _u64, _i, _vp, _i64, _vp]),
+    "eeseg_lovasz": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp, _f, _vp, _u64, _i, _i, _vp, _vp, _vp, _i64, _vp]),
+    "eeseg_label_hist": (_i, [_vp, _i64, _i, _i64, _vp, _vp]),
     "eeseg_sgd_step": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _i, _vp]),
     "eeseg_comm_available": (_i, [C.POINTER(_i)]),
     "eeseg_comm_unique_id": (_i, [_vp]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "eeseg_comm_all_reduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "eeseg_comm_all_gather": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "eeseg_comm_broadcast": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "eeseg_comm_reduce_scatter": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
 }
 
 _lib = None

@@ -41,6 +41,47 @@ class _LovaszFn(torch.autograd.Function):
         return ds * g, None, None, None
 
 
+class _LovaszShareFn(torch.autograd.Function):
+    """This rank's share of the whole batch's Lovasz loss under class-sharded data parallelism: sum over ITS classes of
+    loss_c, divided by the number of classes in the mean (`norm`, a device int32).  `scores` holds one plane per owned
+    class, `class_ids` says which label class each plane ranks, labels of every other class are valid background."""
+
+    @staticmethod
+    def forward(ctx, scores, target, ignore, class_ids, n_label, present, norm):
+        scores = scores.contiguous()
+        need = scores.requires_grad or torch.is_grad_enabled()
+        loss, ds = K.lovasz(scores.detach(), target, ignore, want_grad=need, classes="present" if present else "all",
+                            n_label_classes=n_label, class_ids=class_ids, norm_classes_dev=norm)
+        ctx.save_for_backward(ds) if ds is not None else None
+        ctx.has = ds is not None
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.has:
+            return (None,) * 7
+        (ds,) = ctx.saved_tensors
+        return (ds * g,) + (None,) * 6
+
+
+class _GatherRowsSummedBack(torch.autograd.Function):
+    """[n, ...] on every rank -> [world*n, ...] (rank-major).  Backward for losses of which every rank evaluates a SHARE on the
+    whole batch (class-sharded Lovasz): the gradient of this rank's rows is the SUM over the ranks of their gradients of those
+    rows (reduce-scatter), times world because the data-parallel reducer averages the parameter gradients over the ranks."""
+
+    @staticmethod
+    def forward(ctx, t, cfg):
+        ctx.cfg, ctx.n = cfg, t.shape[0]
+        return cfg.all_gather(t.contiguous()).flatten(0, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg, n = ctx.cfg, ctx.n
+        world = cfg.dp_world()
+        mine = cfg.reduce_scatter(g.contiguous().view(world, n, *g.shape[1:]))
+        return mine * float(world), None
+
+
 def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
     """lovaszsoftmax.py:154-169.  classes: 'present', 'all' or a list of class indices (:185-188).  per_image=True
     (:165-166): every image is ranked alone and the per-image losses are averaged - one segmented sort per image (the
@@ -60,16 +101,22 @@ def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=No
 class LovaszSoftmax(nn.Module):
     """Data-parallel runs: ``per_image=False`` ranks all pixels of the batch JOINTLY (branchy_seg_losses.py:134,154;
     lovaszsoftmax.py:172-200), so the loss of a sharded batch is not a function of per-shard losses.  The default
-    (`per_shard=False`) is therefore exact: every rank all-gathers the exits' low-resolution logits and the labels
-    (a few MB), evaluates the loss of the WHOLE batch and back-propagates its own images' part (engine.AllGatherRows);
-    the sort is redundant across ranks - that is the price of the reference's joint ranking.  `per_shard=True` ranks
+    (`per_shard=False`) is exact AND non-redundant (round 4): the loss is a mean over classes of per-class losses that are
+    independent given all pixels, so the ranks share the CLASSES - every rank all-gathers the exits' low-resolution logits
+    and the labels (a few MB; 10x less than moving the full-resolution (error, flag) pairs of a key-range partition would),
+    upsamples and ranks only classes r, r + world, ... over the whole batch (sort keys per rank = P_global * C / world =
+    its own pixels' worth), the scalar shares are summed, and the low-resolution logit gradients go back by ONE
+    reduce-scatter per exit (each rank receives the summed gradient of its own images).  `class_sharded=False` keeps the
+    round-2/3 form (every rank ranks every class of the whole batch: world times the sort work).  `per_shard=True` ranks
     each rank's pixels alone (cheaper, a documented deviation).  `comm`: engine.Config whose group is used when the
     prediction is a plain tensor (an ExitLogits carries its network's)."""
 
     def __init__(self, classes="present", per_image=False, ignore=None, n_branches=0, prev_out=False, per_shard=False,
-                 comm=None):
+                 comm=None, class_sharded=True):
         super().__init__()
         self.classes, self.per_image, self.ignore = classes, per_image, ignore
+        self.class_sharded = class_sharded
+        self.last_sort_keys = None       # elements this rank ranked in the last forward call, per exit (tests / INTEGRATION)
         self.n = n_branches + 1
         self.prev_out = prev_out
         self.per_shard = per_shard
@@ -92,6 +139,8 @@ class LovaszSoftmax(nn.Module):
         if gather:
             t = targets.squeeze(1) if targets.dim() > 3 else targets
             targets = comm.all_gather(t.contiguous()).flatten(0, 1)
+        if gather and self.class_sharded and isinstance(y_pred, ExitLogits):
+            return self._forward_class_sharded(y_pred, targets.contiguous().long(), comm)
         for i in range(self.n):
             if gather and isinstance(y_pred, ExitLogits):
                 from .from_deepv3_new import upsample_logits
@@ -106,6 +155,48 @@ class LovaszSoftmax(nn.Module):
         if self.prev_out:
             return torch.dot(self.weights.to(losses.device), losses).sum()
         return losses.sum()
+
+
+def _forward_class_sharded(self, y_pred, targets, comm):
+    """LovaszSoftmax.forward for a data-parallel run, exact and non-redundant (class docstring).  `targets`: the gathered
+    labels of the whole batch [N_global, H, W]."""
+    from .from_deepv3_new import upsample_logits
+    world, rank = comm.dp_world(), comm.dp_rank()
+    C_ = y_pred.num_classes
+    dev = targets.device
+    cand = list(range(C_)) if isinstance(self.classes, str) else [int(c) for c in self.classes]
+    own = cand[rank::world]                        # round-robin over the classes of the mean
+    present = self.classes == "present"
+    if present:                                     # number of classes in the mean = classes present in the WHOLE batch
+        norm = torch.count_nonzero(K.label_hist(targets, C_, self.ignore)).to(torch.int32).reshape(1)
+    else:
+        norm = torch.full((1,), len(cand), dtype=torch.int32, device=dev)
+    idx = torch.tensor(own, dtype=torch.long, device=dev)
+    shares, keys = [], []
+    for i in range(self.n):
+        lr = _GatherRowsSummedBack.apply(y_pred.lowres[i], comm)          # [N_global, h, w, CPAD], every class
+        if own:
+            planes = torch.zeros(lr.shape[:-1] + (lr.shape[-1],), dtype=lr.dtype, device=dev).index_copy(
+                -1, torch.arange(len(own), device=dev), lr.index_select(-1, idx))      # owned classes in the leading planes
+            yi = upsample_logits(planes, len(own), y_pred.size)          # [N_global, C_own, H, W]
+            shares.append(_LovaszShareFn.apply(yi, targets, self.ignore, own, C_, present, norm).unsqueeze(0))
+            keys.append(int(yi.shape[0] * yi.shape[1] * yi.shape[2] * yi.shape[3]))
+        else:                                       # more ranks than classes: nothing to rank, but every rank joins the collectives
+            shares.append((lr.sum() * 0.0).unsqueeze(0))
+            keys.append(0)
+    self.last_sort_keys = keys
+    shares = torch.cat(shares)
+    total = shares.detach().clone()
+    comm.all_reduce(total)                          # the value every rank reports: the whole batch's loss of every exit
+    losses = shares + (total - shares.detach()) / float(world) * 0.0 + (total - shares.detach())
+    # (value = total; gradient = this rank's share's)  NB: the data-parallel reducer AVERAGES rank gradients and
+    # _GatherRowsSummedBack multiplies by world, so the parameter gradients are those of `total`
+    if self.prev_out:
+        return torch.dot(self.weights.to(losses.device), losses).sum()
+    return losses.sum()
+
+
+LovaszSoftmax._forward_class_sharded = _forward_class_sharded
 
 
 # --------------------------------------------------------------------------------------------------------------

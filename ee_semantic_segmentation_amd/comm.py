@@ -115,6 +115,16 @@ class Communicator:
                                           t.numel() * t.element_size(), self._stream(stream)), "comm_all_gather")
         return out
 
+    def reduce_scatter(self, t, op=SUM, stream=None):
+        """t [world, ...] on every rank -> this rank's slice [...] of the element-wise reduction over the ranks."""
+        self._ok(t)
+        assert t.shape[0] == self.world
+        self.calls += 1
+        out = torch.empty(t.shape[1:], dtype=t.dtype, device=t.device)
+        check(lib().eeseg_comm_reduce_scatter(self._h, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
+                                              _DTYPES[t.dtype], op, self._stream(stream)), "comm_reduce_scatter")
+        return out
+
     def broadcast(self, t, root=0, stream=None):
         self._ok(t)
         check(lib().eeseg_comm_broadcast(self._h, C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), root,
@@ -189,6 +199,15 @@ class DataParallelComm:
         else:
             self.stat.all_reduce(t)
         return t
+
+    def stat_reduce_scatter(self, t):
+        if self.single_lane:
+            self.lane_g.fork()
+            out = self.stat.reduce_scatter(t, stream=self.lane_g.stream)
+            self.lane_g.busy = True
+            self.lane_g.join()
+            return out
+        return self.stat.reduce_scatter(t)
 
     def stat_all_gather(self, t):
         if self.single_lane:

@@ -32,6 +32,7 @@ typedef const char* (*fn_error_string)(int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
 typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
+typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
 
 struct Rccl {
     void* handle = nullptr;
@@ -44,6 +45,7 @@ struct Rccl {
     fn_all_reduce all_reduce = nullptr;
     fn_all_gather all_gather = nullptr;
     fn_broadcast broadcast = nullptr;
+    fn_reduce_scatter reduce_scatter = nullptr;
     char where[96] = "";
 };
 
@@ -75,6 +77,7 @@ void bind_rccl() {
     EESEG_SYM(all_reduce, "ncclAllReduce")
     EESEG_SYM(all_gather, "ncclAllGather")
     EESEG_SYM(broadcast, "ncclBroadcast")
+    EESEG_SYM(reduce_scatter, "ncclReduceScatter")
 #undef EESEG_SYM
     g_rccl = r;
 }
@@ -203,6 +206,16 @@ int eeseg_comm_all_gather(void* comm, const void* send, void* recv, int64_t byte
     EESEG_CHECK(send && recv && bytes_per_rank > 0, EESEG_ERR_ARG, "comm_all_gather: empty buffer");
     EESEG_RCCL(R, R->all_gather(send, recv, (size_t)bytes_per_rank, /*ncclUint8*/ 1, c->comm, static_cast<hipStream_t>(stream)),
                "ncclAllGather");
+    return EESEG_OK;
+}
+
+int eeseg_comm_reduce_scatter(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, int op, void* stream) {
+    EESEG_COMM_ARG(c, comm);
+    const int dt = nccl_dtype(dtype), o = nccl_op(op);
+    EESEG_CHECK(dt >= 0 && o >= 0, EESEG_ERR_ARG, "comm_reduce_scatter: dtype %d / op %d", dtype, op);
+    EESEG_CHECK(send && recv && count_per_rank > 0, EESEG_ERR_ARG, "comm_reduce_scatter: empty buffer");
+    EESEG_RCCL(R, R->reduce_scatter(send, recv, (size_t)count_per_rank, dt, o, c->comm, static_cast<hipStream_t>(stream)),
+               "ncclReduceScatter");
     return EESEG_OK;
 }
 

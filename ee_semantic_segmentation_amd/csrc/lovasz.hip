@@ -19,15 +19,19 @@ namespace {
 
 constexpr int SB = 2048;          // elements per scan block (256 threads x 8)
 
+struct LvClassIds { short id[64]; };   // label class ranked as class c (identity unless the caller ranks a subset, eeseg_lovasz class_ids)
+
 struct LvHeader {                 // lives at the start of the workspace
     int n_valid;
     int n_present;
     int pad[2];
 };
 
+// n_label >= C: labels in [0, n_label) are valid pixels; only labels < C are the foreground of a ranked class (a rank of a
+// class-sharded data-parallel Lovasz ranks ITS classes, remapped to 0 .. C-1, over pixels of every class)
 __global__ __launch_bounds__(256) void lv_prep(const float* __restrict__ scores, const int64_t* __restrict__ target,
-                                               int N, int C, int HW, long long ignore, float* keys, unsigned* vals,
-                                               int* G, LvHeader* hdr) {
+                                               int N, int C, int HW, long long ignore, int n_label, LvClassIds ids, float* keys,
+                                               unsigned* vals, int* G, LvHeader* hdr) {
     __shared__ int sG[64];
     __shared__ int sValid;
     for (int i = threadIdx.x; i < 64; i += blockDim.x) sG[i] = 0;
@@ -36,24 +40,27 @@ __global__ __launch_bounds__(256) void lv_prep(const float* __restrict__ scores,
     const long long P = (long long)N * HW;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
         const long long t = target[p];
-        const bool valid = (t != ignore) && t >= 0 && t < C;
+        const bool valid = (t != ignore) && t >= 0 && t < n_label;
         const int n = (int)(p / HW);
         const int hw = (int)(p - (long long)n * HW);
+        int mine = -1;                                      // the ranked class this pixel is foreground of, if any
         for (int c = 0; c < C; ++c) {
             float key = -1.f;
             unsigned v = (unsigned)p;                       // p < 2^30 (P*C < 2^31, C >= 2): bits 30/31 are free
+            const bool fg = valid && t == (long long)ids.id[c];
             if (valid) {
                 const float s = scores[((size_t)n * C + c) * HW + hw];
-                const float d = (t == c ? 1.f : 0.f) - s;
+                const float d = (fg ? 1.f : 0.f) - s;
                 key = fabsf(d);
                 if (d < 0.f) v |= 0x80000000u;              // sign of (fg - s)
-                if (t == c) v |= 0x40000000u;               // foreground flag travels with the element
+                if (fg) v |= 0x40000000u;                   // foreground flag travels with the element
             }
+            if (fg) mine = c;
             keys[(size_t)c * P + p] = key;
             vals[(size_t)c * P + p] = v;
         }
         if (valid) {
-            atomicAdd(&sG[(int)t], 1);
+            if (mine >= 0) atomicAdd(&sG[mine], 1);
             atomicAdd(&sValid, 1);
         }
     }
@@ -254,7 +261,8 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
                                                 const int64_t* __restrict__ target, long long P, int nblk, int C,
                                                 int HW, const int* __restrict__ G, const int* __restrict__ bsum,
                                                 const LvHeader* hdr, double* class_loss, float* dscores, float gscale,
-                                                const float* gscale_dev, unsigned long long class_mask, int present_only) {
+                                                const float* gscale_dev, unsigned long long class_mask, int present_only,
+                                                const int* norm_dev) {
     __shared__ int swave[4];
     __shared__ double sloss[4];
     const int c = blockIdx.y, b = blockIdx.x;
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
     for (int w = 0; w < wave; ++w) base += swave[w];
     int F = base + incl - local;                           // foreground count before my first element
     const float scale = (dscores != nullptr)
-                            ? gscale * (gscale_dev ? gscale_dev[0] : 1.f) / (float)max(hdr->n_present, 1) : 0.f;
+                            ? gscale * (gscale_dev ? gscale_dev[0] : 1.f) / (float)max(norm_dev ? norm_dev[0] : hdr->n_present, 1) : 0.f;
     double part = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -320,15 +328,33 @@ __global__ __launch_bounds__(256) void lv_final(const float* __restrict__ keys, 
     if (threadIdx.x == 0) atomicAdd(&class_loss[c], sloss[0] + sloss[1] + sloss[2] + sloss[3]);
 }
 
+// norm_dev (optional): the number of classes the mean runs over, from the caller (class-sharded data parallelism: this call
+// ranks a SUBSET of the classes and returns its share sum_c loss_c / norm - the shares of the ranks add up to the loss)
 __global__ void lv_loss(const double* class_loss, const int* G, int C, const LvHeader* hdr, float* loss_out,
-                        unsigned long long class_mask, int present_only) {
+                        unsigned long long class_mask, int present_only, const int* norm_dev) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double s = 0.0;
         int n = 0;
         for (int c = 0; c < C; ++c)
             if (lv_counted(c, G[c], class_mask, present_only)) { s += class_loss[c]; ++n; }
+        if (norm_dev) n = n ? norm_dev[0] : 0;
         loss_out[0] = (n && hdr->n_valid > 0) ? (float)(s / n) : 0.f;   // only void pixels: 0 (lovaszsoftmax.py:181-183)
     }
+}
+
+// counts[c] = number of pixels labelled c (c < C; `ignore` and out-of-range labels skipped): which classes are present
+__global__ __launch_bounds__(256) void label_hist_kernel(const int64_t* __restrict__ target, long long P, int C, long long ignore,
+                                                         int* counts) {
+    __shared__ int sh[64];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const long long t = target[p];
+        if (t != ignore && t >= 0 && t < C) atomicAdd(&sh[(int)t], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x)
+        if (sh[i]) atomicAdd(&counts[i], sh[i]);
 }
 
 struct Layout {
@@ -362,10 +388,34 @@ extern "C" int64_t eeseg_lovasz_workspace(int64_t P, int C) {
     return (int64_t)layout(P, C).total;
 }
 
+extern "C" int eeseg_label_hist(const int64_t* target, int64_t n, int C, int64_t ignore_index, int32_t* counts, void* stream) {
+    EESEG_CHECK(target && counts && n > 0 && C > 0 && C <= 64, EESEG_ERR_ARG, "label_hist: bad argument (C <= 64)");
+    hipStream_t st = (hipStream_t)stream;
+    EESEG_HIP(hipMemsetAsync(counts, 0, (size_t)C * sizeof(int32_t), st));
+    long long pb = (n + 255) / 256;
+    if (pb > 2048) pb = 2048;
+    hipLaunchKernelGGL(label_hist_kernel, dim3((unsigned)pb), dim3(256), 0, st, target, (long long)n, C, (long long)ignore_index, counts);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
 extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
                             float* loss_out, float* dscores, float gscale, const float* gscale_dev, uint64_t class_mask,
-                            int present_only, void* workspace, int64_t workspace_bytes, void* stream) {
+                            int present_only, int n_label_classes, const int32_t* class_ids, const int32_t* norm_classes_dev,
+                            void* workspace, int64_t workspace_bytes, void* stream) {
     EESEG_CHECK(scores && target && loss_out && workspace, EESEG_ERR_ARG, "lovasz: null pointer");
+    if (n_label_classes <= 0) n_label_classes = C;
+    EESEG_CHECK(n_label_classes >= C && n_label_classes <= 32767, EESEG_ERR_ARG, "lovasz: n_label_classes must be in [C, 32767]");
+    EESEG_CHECK(C <= 64, EESEG_ERR_ARG, "lovasz: C <= 64");
+    LvClassIds ids;
+    for (int c = 0; c < 64; ++c) ids.id[c] = (short)c;
+    if (class_ids) {
+        for (int c = 0; c < C; ++c) {
+            EESEG_CHECK(class_ids[c] >= 0 && class_ids[c] < n_label_classes, EESEG_ERR_ARG, "lovasz: class_ids[%d] = %d outside [0, %d)",
+                        c, class_ids[c], n_label_classes);
+            ids.id[c] = (short)class_ids[c];
+        }
+    }
     EESEG_CHECK(present_only == 0 || present_only == 1, EESEG_ERR_ARG, "lovasz: present_only must be 0 or 1");
     EESEG_CHECK(N > 0 && C > 0 && C <= 64 && HW > 0, EESEG_ERR_ARG, "lovasz: bad shape (C <= 64)");
     const long long P = (long long)N * HW;
@@ -391,7 +441,7 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     long long pb = (P + 255) / 256;
     if (pb > 4096) pb = 4096;
     hipLaunchKernelGGL(lv_prep, dim3((unsigned)pb), dim3(256), 0, st, scores, target, N, C, HW, (long long)ignore_index,
-                       keys_in, vals_in, G, hdr);
+                       n_label_classes, ids, keys_in, vals_in, G, hdr);
     EESEG_LAUNCH_CHECK();
     // 4 x 8-bit LSD passes, ping-pong between the two buffer pairs
     const int ntile = (int)((P + RT - 1) / RT);
@@ -416,8 +466,8 @@ extern "C" int eeseg_lovasz(const float* scores, const int64_t* target, int N, i
     const unsigned long long cm = (unsigned long long)class_mask;
     hipLaunchKernelGGL(lv_count_present, dim3(1), dim3(64), 0, st, C, G, hdr, cm, present_only);
     hipLaunchKernelGGL(lv_final, dim3(nblk, C), dim3(256), 0, st, keys_out, vals_out, target, P, nblk, C, HW, G, bsum, hdr,
-                       closs, dscores, gscale, gscale_dev, cm, present_only);
-    hipLaunchKernelGGL(lv_loss, dim3(1), dim3(64), 0, st, closs, G, C, hdr, loss_out, cm, present_only);
+                       closs, dscores, gscale, gscale_dev, cm, present_only, norm_classes_dev);
+    hipLaunchKernelGGL(lv_loss, dim3(1), dim3(64), 0, st, closs, G, C, hdr, loss_out, cm, present_only, norm_classes_dev);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

@@ -104,6 +104,14 @@ class Config:
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
         return out
 
+    def reduce_scatter(self, t):
+        """t [world, ...] on every rank -> this rank's slice of the sum over the ranks.  Test hook / host tensors: an
+        all-reduce followed by the slice (same result, world times the traffic)."""
+        if self.comm is not None and self.collective is None:
+            return self.comm.stat_reduce_scatter(t.contiguous())
+        full = self.all_reduce(t.contiguous().clone())
+        return full[self.dp_rank()].clone()
+
     def all_reduce(self, t):
         """Sum `t` over the data-parallel group in place, on the compute stream.  Transports: the RCCL communicator
         (`comm`, the product), the `collective` test hook (callable(t, group): the world-2 parity tests stage device

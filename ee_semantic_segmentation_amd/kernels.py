@@ -859,9 +859,22 @@ def gather_images(x, src_slot, n_active):
     return y
 
 
-def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None, classes="present"):
+def label_hist(target, C_, ignore_index):
+    """-> int32 [C]: pixels labelled c (labels == ignore_index or outside [0, C) skipped)."""
+    _need_cuda(target)
+    assert target.is_contiguous() and target.dtype == torch.int64
+    counts = torch.empty(C_, dtype=torch.int32, device=target.device)
+    check(lib().eeseg_label_hist(_p(target), target.numel(), C_, int(-1 if ignore_index is None else ignore_index), _p(counts),
+                                 _stream()), "eeseg_label_hist")
+    return counts
+
+
+def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev=None, classes="present", n_label_classes=0,
+           class_ids=None, norm_classes_dev=None):
     """scores [N,C,H,W] fp32 contiguous, target [N,H,W] int64.  Returns (loss[1], dscores|None).
-    classes: 'present' | 'all' | list of class indices (lovaszsoftmax.py:185-188)."""
+    classes: 'present' | 'all' | list of class indices (lovaszsoftmax.py:185-188).
+    n_label_classes / class_ids / norm_classes_dev: ranking a subset of the label classes - the class-sharded data-parallel
+    form (eeseg.h, eeseg_lovasz): score plane c ranks label class class_ids[c]."""
     _need_cuda(scores, target)
     N, C_, H, W = scores.shape
     assert scores.is_contiguous() and scores.dtype == torch.float32
@@ -883,7 +896,11 @@ def lovasz(scores, target, ignore_index, want_grad=False, gscale=1.0, gscale_dev
             if not 0 <= int(c) < C_:
                 raise _lib.EesegError(f"lovasz: class {c} outside [0, {C_})")
             mask |= 1 << int(c)
+    ids = None
+    if class_ids is not None:
+        assert len(class_ids) == C_
+        ids = (C.c_int32 * C_)(*[int(c) for c in class_ids])
     check(lib().eeseg_lovasz(_p(scores), _p(target), N, C_, H * W, int(-1 if ignore_index is None else ignore_index),
-                             _p(loss), _p(ds), float(gscale), _p(gscale_dev), mask, present_only, _p(ws), ws.numel(),
-                             _stream()), "eeseg_lovasz")
+                             _p(loss), _p(ds), float(gscale), _p(gscale_dev), mask, present_only, int(n_label_classes),
+                             ids, _p(norm_classes_dev), _p(ws), ws.numel(), _stream()), "eeseg_lovasz")
     return loss, ds

@@ -391,9 +391,17 @@ int eeseg_entropy_gate(const float* logits_lr, int ldc, int N, int C, int h, int
  * Ties between equal errors are ordered by pixel index (torch.sort leaves them
  * unspecified); the loss value is tie-invariant. */
 int64_t eeseg_lovasz_workspace(int64_t P, int C);
+/* Ranking a SUBSET of the label classes (round 4, the class-sharded data-parallel form): n_label_classes (0 = C): labels in
+ * [0, n_label_classes) are valid pixels; class_ids (HOST int32[C], NULL = identity): score plane c ranks label class
+ * class_ids[c]; norm_classes_dev (NULL = none): DEVICE int32, the number of classes the mean runs over - the call then
+ * returns sum_c loss_c / norm over ITS classes.  The per-class losses are independent given all pixels, so rank r ranks
+ * classes r, r + world, ... over the gathered batch and the ranks' shares add up to the reference's loss - exact, and no
+ * rank sorts more than its share.  eeseg_label_hist: counts[c] = pixels labelled c (which classes are 'present'). */
+int eeseg_label_hist(const int64_t* target, int64_t n, int C, int64_t ignore_index, int32_t* counts, void* stream);
 int eeseg_lovasz(const float* scores, const int64_t* target, int N, int C, int HW, int64_t ignore_index,
                  float* loss_out, float* dscores, float gscale, const float* gscale_dev, uint64_t class_mask,
-                 int present_only, void* workspace, int64_t workspace_bytes, void* stream);
+                 int present_only, int n_label_classes, const int32_t* class_ids, const int32_t* norm_classes_dev,
+                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------- SGD ------
  * torch.optim.SGD(momentum, weight_decay) step, multi-tensor
@@ -447,6 +455,9 @@ int eeseg_comm_all_reduce(void* comm, void* buf, int64_t count, int dtype, int o
 int eeseg_comm_all_gather(void* comm, const void* send, void* recv /* [world][bytes_per_rank] */, int64_t bytes_per_rank,
                           void* stream);
 int eeseg_comm_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
+/* recv[count_per_rank] = rank r's slice of the element-wise reduction of every rank's send[world * count_per_rank] (the
+ * class-sharded exact Lovasz hands each rank the summed low-resolution logit gradients of ITS images) */
+int eeseg_comm_reduce_scatter(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, int op, void* stream);
 
 #ifdef __cplusplus
 }

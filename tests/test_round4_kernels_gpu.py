@@ -327,3 +327,39 @@ def test_wgrad_in_kernel_combine_is_reproducible_and_matches_atomics_and_torch(s
     st = K.coop_state(xd.device, "wgrad")
     torch.cuda.synchronize()
     assert torch.count_nonzero(st).item() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("classes", ["present", "all", [0, 2, 3, 5]], ids=["present", "all", "list"])
+def test_lovasz_class_shares_add_up_to_the_whole_loss(classes):
+    """eeseg_lovasz with class_ids / n_label_classes / norm_classes_dev (the class-sharded data-parallel form): ranking classes
+    r, r + world, ... separately - every pixel still valid, foreign labels as background - and dividing by the number of classes
+    of the WHOLE mean gives shares whose sum is the loss of one call over all classes, and whose gradients are that call's
+    gradient planes, bit for bit (same keys, same sort, same Jaccard increments per class)."""
+    C_, N, H, W = 7, 2, 37, 41
+    g = torch.Generator().manual_seed(11)
+    scores = torch.randn(N, C_, H, W, generator=g).to(DEV)
+    target = torch.randint(0, C_ + 1, (N, H, W), generator=g)
+    target[target == 4] = 1                                      # class 4 absent ('present' drops it, 'all' keeps it)
+    target = target.to(DEV)
+    ignore = C_
+    loss, ds = K.lovasz(scores, target, ignore, want_grad=True, classes=classes)
+    cand = list(range(C_)) if isinstance(classes, str) else list(classes)
+    counts = K.label_hist(target, C_, ignore)
+    assert counts.tolist() == [int((target == c).sum()) for c in range(C_)]
+    if classes == "present":
+        norm = torch.count_nonzero(counts).to(torch.int32).reshape(1)
+    else:
+        norm = torch.full((1,), len(cand), dtype=torch.int32, device=DEV)
+    world = 3
+    total = 0.0
+    ds_sh = torch.zeros_like(ds)
+    for r in range(world):
+        own = cand[r::world]
+        sub = scores[:, own].contiguous()
+        l_r, d_r = K.lovasz(sub, target, ignore, want_grad=True, classes="present" if classes == "present" else "all",
+                            n_label_classes=C_, class_ids=own, norm_classes_dev=norm)
+        total += float(l_r.item())
+        ds_sh[:, own] = d_r
+    assert abs(total - float(loss.item())) <= 2e-6 * abs(float(loss.item())), (total, float(loss.item()))
+    assert torch.equal(ds_sh, ds)
