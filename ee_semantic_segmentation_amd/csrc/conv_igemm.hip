@@ -1500,8 +1500,19 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
         // 30-us loop when issued one after the other)
         auto step = [&](int t, const Frag (&ac)[2][2], const Frag (&bc)[J][2], Frag (&an)[2][2], Frag (&bn)[J][2], bool first) {
             // K tile t+1 landed (tiles t+2 .. t+NST-1 stay in flight) and this wave holds the fragments of tile t
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(6 * (NST - 2)) : "memory");
+#ifdef EESEG_PW_CYCLES    // diagnostic build: shader-clock stamps of K tiles 16..19, block 0, per wave, behind the per-block stamps
+#define PW_CYC(i) if (blockIdx.x == 0 && lane == 0 && p.slabs && t >= 16 && t < 20) \
+    reinterpret_cast<unsigned long long*>(p.slabs)[8192 + ((t - 16) * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define PW_CYC(i)
+#endif
+            PW_CYC(0);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (NST - 2)) : "memory");
+            PW_CYC(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PW_CYC(2);
             BIG_BARRIER();                                     // ... as does every wave: tile t's stage is free
+            PW_CYC(3);
             const int kt = t + NST;
             const bool live = kt < nk;
             const int soffX = TAPS ? it_ci * PW_ROW : kt * PW_ROW, sW = kt * PW_ROW;
@@ -1547,6 +1558,7 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            PW_CYC(4);
             if constexpr (TAPS) {                              // the issue-side iterator: on to K tile kt + 1
                 if (++it_ci == nkc) {
                     it_ci = 0;
