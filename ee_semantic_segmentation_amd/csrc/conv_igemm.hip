@@ -2025,6 +2025,549 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing out-of-range DMAs still write into LDS
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Round 4: the same weight-stationary layer with the two halves of the work on DIFFERENT waves.  In conv_pws_kernel every wave
+// alternates between 64 MFMAs and the epilogue of what it has just computed (stage, read back, residual, store, statistics),
+// five barriers per half tile, and only the second block of the CU fills the gaps: 107 us per call where the MFMAs need 32 us and
+// HBM 63 us.  Here a block has 8 waves, one block per CU: waves 0-3 hold the weights and do nothing but LDS-DMA, MFMA and the
+// bf16 staging of 32-pixel sub-tiles; waves 4-7 turn the previous sub-tile's staged output into stores (residual, ReLU, BN
+// partial sums).  One LDS-only barrier per sub-tile hands a staging slot over (two slots), the activations arrive through a
+// four-slot ring issued three sub-tiles ahead (counted vmcnt on the MFMA waves, whose only vector memory traffic it is), and the
+// residual rows of the output waves are requested three rounds ahead into a register ring.  Same MFMAs in the same order, same
+// order of every sum as conv_pws_kernel: bit-identical outputs and statistics.
+constexpr int W2_SUB = 32;                          // pixels per sub-tile
+constexpr int W2_SLOT = W2_SUB * WS_ROWB;           // 16 KiB
+constexpr int W2_XS = 4, W2_SS = 2;
+constexpr int W2_RED = (W2_XS + W2_SS) * W2_SLOT;   // [4 waves][2][256] floats behind the slots
+constexpr int W2_LDS = W2_RED + 4 * 2 * 256 * 4 + 16;
+
+template <bool RES, int NMW, int NOW>
+__global__ __launch_bounds__((NMW + NOW) * 64, 1) void conv_pws2_kernel(ConvP p) {
+    typedef bf16_t T;
+    typedef Mma<T>::Frag Frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __shared__ __attribute__((aligned(16))) char smem[W2_RED + NOW * 2 * 256 * 4 + 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = 8 * p.n_tiles;
+    const int grp = blockIdx.x / per, g = blockIdx.x % per;
+    const int nt = g >> 3, seq = grp * 8 + (g & 7), nseq = (gridDim.x / per) * 8;
+    const int n0 = nt * 256;
+    const int n_m = p.m_tiles;                                   // 128-pixel tiles (= BN statistic rows)
+    // sub-tile t of this block = rows (t & 3) * 32 ... of the 128-pixel tile seq + (t >> 2) * nseq; T4 of them.  Both wave roles
+    // run T4 + 1 rounds (the output waves trail by one) and one closing barrier: the same number of s_barrier on every wave.
+    const int T4 = seq < n_m ? 4 * ((n_m - seq + nseq - 1) / nseq) : 0;
+    char* const sS = smem + W2_XS * W2_SLOT;
+    float* const sRed = reinterpret_cast<float*>(smem + W2_RED);
+
+#ifdef EESEG_PW_CYCLES    // diagnostic build: shader-clock time per phase, summed over the rounds, waves 0 and 4 of every 37th block
+    long long cyc_t[6] = {0, 0, 0, 0, 0, 0}, cyc_last = 0;
+#define W2_CYC(i) { const long long now_ = (long long)__builtin_readcyclecounter(); if ((i) > 0 || cyc_last) cyc_t[(i)] += now_ - cyc_last; cyc_last = now_; }
+#define W2_CYC_OUT(role) if (lane == 0 && p.slabs && blockIdx.x % 37 == 0 && (wave == 0 || wave == NMW)) { \
+        long long* d_ = reinterpret_cast<long long*>(p.slabs) + 8192 + ((blockIdx.x / 37) * 2 + (role)) * 8; \
+        d_[0] = cyc_t[0]; d_[1] = cyc_t[1]; d_[2] = cyc_t[2]; d_[3] = cyc_t[3]; d_[4] = T4; d_[5] = cyc_t[4]; d_[6] = cyc_t[5]; }
+#else
+#define W2_CYC(i)
+#define W2_CYC_OUT(role)
+#endif
+#ifdef EESEG_W2_WHATIF    // what-if switches of a diagnostic build (EESEG_W2_VAR): each leaves one piece of a round out
+    const int var = p.tap_inner;
+#else
+    constexpr int var = 0;
+#endif
+    constexpr int NI = 8 / NMW;                                  // 32-cout blocks per MFMA wave (NMW = 4: 64 couts, 8: 32 couts)
+    constexpr int ND = 16 / NMW;                                 // LDS-DMA instructions per MFMA wave and sub-tile
+    if (wave < NMW) {
+        // ------------------------------- MFMA waves -------------------------------
+        const int fr_ = lane & 31, fh_ = lane >> 5, fx_ = fr_ & 15;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+        // one wave instruction = 2 rows x 512 B; instruction q of wave w covers rows (w*ND+q)*2 + (lane>>5) of the sub-tile
+        auto issue = [&](int t) {
+            int drow = lane >> 5, dslot = lane & 31;
+            asm volatile("" : "+v"(drow), "+v"(dslot));          // recomputed per call: no hoisted addresses beside the weights
+            char* sx = smem + (t & 3) * W2_SLOT;
+            const int mb = (seq + (t >> 2) * nseq) * 128 + (t & 3) * W2_SUB;
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const int r = (wave * ND + q) * 2 + drow;
+                const int m = mb + r;
+                const uint32_t voff = (t < T4 && m < p.M) ? (uint32_t)(m * WS_ROWB + ((dslot ^ (r & 15)) << 4)) : EESEG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * ND + q) * 1024), 16, (int)voff, 0, 0, 0);
+            }
+        };
+        Frag a[NI][16];                                           // this wave's couts, all of K, as A fragments
+        {
+            const T* w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const T* wr = w + (size_t)(n0 + wave * (NI * 32) + i * 32 + fr_) * WS_K + fh_ * 8;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(wr + ks * 16);
+            }
+        }
+        issue(0);
+        issue(1);
+        issue(2);
+#pragma unroll 1
+        for (int t = 0; t <= T4; ++t) {
+            W2_CYC(0);
+            if (NMW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // sub-tile t landed (t+1, t+2 in flight); the weights are older still
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            W2_CYC(1);
+            WS_LDS_BARRIER();                                     // ... for every wave; staging slot t & 1 has been read back
+            W2_CYC(2);
+            if (!(var & 32)) issue(t + 3);                        // into the slot round t - 1 consumed (zero-fill past the end)
+            W2_CYC(3);
+            if (t < T4) {
+                int fr = fr_, fh = fh_, fx = fx_;
+                asm volatile("" : "+v"(fr), "+v"(fh), "+v"(fx));
+                const char* r = smem + (t & 3) * W2_SLOT + fr * WS_ROWB;
+                f32x16 acc[NI];
+                // 2 k-steps at a time, the B fragments of the NEXT pair requested before the MFMAs of this one: the wave is alone
+                // (or one of two) on its SIMD's matrix pipe, a read -> wait -> MFMA chain would idle the pipe for the LDS latency
+                // eight times per sub-tile
+                Frag b[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[0][u] = *reinterpret_cast<const Frag*>(r + (((u * 2 + fh) ^ fx) << 4));
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    if (kk < 7) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            b[(kk + 1) & 1][u] = *reinterpret_cast<const Frag*>(r + (((((kk + 1) * 2 + u) * 2 + fh) ^ fx) << 4));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (var & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            if (kk == 0 && u == 0) {
+                                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0][0], z, 0, 0, 0);
+                            } else {
+                                Mma<T>::run(a[i][kk * 2 + u], b[kk & 1][u], acc[i]);
+                            }
+                        }
+                    if (var & 1) __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                W2_CYC(4);
+                // stage [px][cout] as bf16 (16-byte chunks XOR-ed with px & 15, as conv_pws_kernel)
+                char* slot = sS + (t & 1) * W2_SLOT;
+                if (var & 8) { if (acc[0][0] == 1.2345f && acc[NI - 1][3] == 7.f) slot[lane] = 1; }
+                else
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        T v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][4 * gq + e]);
+                        const int cl = wave * (NI * 32) + i * 32 + 8 * gq + 4 * fh;
+                        *reinterpret_cast<bf16x4*>(slot + fr * WS_ROWB + ((((cl >> 3) ^ fx) << 4) | ((cl & 4) << 1))) = bf16x4{v[0], v[1], v[2], v[3]};
+                    }
+#ifdef EESEG_PW_CYCLES
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                W2_CYC(5);
+#endif
+            }
+        }
+        W2_CYC(0);
+        WS_LDS_BARRIER();                                         // the closing round of the output waves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // trailing out-of-range DMAs still write into LDS
+        W2_CYC_OUT(0);
+    } else {
+        // ------------------------------- output waves -------------------------------
+        const int ot = tid - NMW * 64, ow = wave - NMW;
+        const int c = ot & 31, r0 = ot >> 5;                      // 16-byte chunk c of rows r0 + RS*it of a sub-tile
+        constexpr int RS = NOW * 2, NR = 32 / RS;                 // row stride and rows per thread (NOW = 4: 8 and 4, 8: 16 and 2)
+        const int cg = n0 + c * 8;
+        const T* res = RES ? reinterpret_cast<const T*>(p.residual) : nullptr;
+        float* const stats = RES ? nullptr : p.stats;
+        T* yout = reinterpret_cast<T*>(p.y);
+        constexpr int RR = RES ? 4 : 1;
+        i32x4 rr[RR][NR];                                          // residual rows, requested three rounds before their use
+        unsigned mb[RR][NR];
+        f32x2 a1[4], a2[4];
+        float stat_half0[2] = {0.f, 0.f};
+        auto row0 = [&](int t) { return (seq + (t >> 2) * nseq) * 128 + (t & 3) * W2_SUB; };
+        auto request = [&](auto kc, int t) {                      // residual (+ mask bytes) of sub-tile t into ring slot K
+            constexpr int K = decltype(kc)::value;
+            if (RES) {
+                const int mh = row0(t);
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    const int m = mh + r0 + RS * it;
+                    const bool ok = t < T4 && m < p.M;
+                    rr[K % RR][it] = ok ? *reinterpret_cast<const i32x4*>(res + (size_t)m * p.ldres + cg) : i32x4{0, 0, 0, 0};
+                    mb[K % RR][it] = (p.resmask && ok) ? p.resmask[(size_t)m * p.ldmask + (cg >> 3)] : 0xffu;
+                }
+            }
+        };
+        // the statistics of a half tile (two sub-tiles) cross the four output waves through sRed one round AFTER they were written
+        auto stats_collect = [&](int t_done) {                    // t_done: the sub-tile whose sums sRed holds (odd)
+            const int col = ot;
+            if (NOW > 4 && col >= 256) return;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                float s = sRed[(0 * 2 + which) * 256 + col] + sRed[(1 * 2 + which) * 256 + col] +
+                          sRed[(2 * 2 + which) * 256 + col] + sRed[(3 * 2 + which) * 256 + col];
+                if (NOW > 4) s += sRed[(4 * 2 + which) * 256 + col] + sRed[(5 * 2 + which) * 256 + col] +
+                                  sRed[(6 * 2 + which) * 256 + col] + sRed[(7 * 2 + which) * 256 + col];
+                if ((t_done & 2) == 0) stat_half0[which] = s;     // first half: kept in a register, one store per tile
+                else stats[((size_t)(seq + (t_done >> 2) * nseq) * 2 + which) * p.Cout + n0 + col] = stat_half0[which] + s;
+            }
+        };
+        auto round = [&](auto kc, int t) {                        // round t: emits sub-tile t - 1 (ring slot K = (t - 1) & 3)
+            constexpr int K = decltype(kc)::value;
+            W2_CYC(0);
+            WS_LDS_BARRIER();
+            W2_CYC(1);
+            request(std::integral_constant<int, (K + 3) % 4>{}, t + 2);
+            if (t < 1) return;
+            const int u = t - 1;
+            if (!RES && stats && u >= 2 && (u & 1) == 0) stats_collect(u - 1);
+            const char* slot = sS + (u & 1) * W2_SLOT;
+            const int mh = row0(u);
+            i32x4 rq[NR];
+            if (var & 64) return;
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int row = r0 + RS * it;
+                rq[it] = *reinterpret_cast<const i32x4*>(slot + row * WS_ROWB + ((c ^ (row & 15)) << 4));
+            }
+            if ((u & 1) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+            }
+#ifdef EESEG_PW_CYCLES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W2_CYC(2);
+#endif
+            if (RES || p.relu) {
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    union { i32x4 q; T e[8]; } v, vr;
+                    v.q = rq[it];
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = to_f32(v.e[e]);
+                    if (RES) {
+                        vr.q = p.resmask ? mask_chunk_bf16(rr[K % RR][it], mb[K % RR][it]) : rr[K % RR][it];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(vr.e[e])));
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(f[e]);
+                    rq[it] = v.q;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int m = mh + r0 + RS * it;
+                if (m < p.M && (!(var & 4) || rq[it][0] == 0x12345)) *reinterpret_cast<i32x4*>(yout + (size_t)m * p.ldy + cg) = rq[it];
+            }
+            W2_CYC(3);
+            if (!RES && stats && !(var & 2)) {
+#pragma unroll
+                for (int it = 0; it < NR; ++it) {
+                    if (mh + r0 + RS * it < p.M) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned w = (unsigned)rq[it][k];
+                            const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                            a1[k] += f;
+                            a2[k] += f * f;
+                        }
+                    }
+                }
+                if (u & 1) {                                      // a half tile is complete: its sums go to sRed (read next round)
+                    float s1[8], s2[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s1[2 * k] = a1[k][0]; s1[2 * k + 1] = a1[k][1];
+                        s2[2 * k] = a2[k][0]; s2[2 * k + 1] = a2[k][1];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1[e] += __shfl_xor(s1[e], 32);
+                        s2[e] += __shfl_xor(s2[e], 32);
+                    }
+                    if (lane < 32) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            sRed[(ow * 2 + 0) * 256 + lane * 8 + e] = s1[e];
+                            sRed[(ow * 2 + 1) * 256 + lane * 8 + e] = s2[e];
+                        }
+                    }
+                }
+            }
+        };
+        request(std::integral_constant<int, 0>{}, 0);
+        request(std::integral_constant<int, 1>{}, 1);
+        // round t uses ring slot (t - 1) & 3 and requests sub-tile t + 2 into slot (t + 2) & 3: four rounds per trip, T4 is a
+        // multiple of 4, so rounds 0 .. T4 are T4 / 4 whole trips and the single round T4 (slot 3)
+#pragma unroll 1
+        for (int t = 0; t < T4; t += 4) {
+            round(std::integral_constant<int, 3>{}, t);
+            round(std::integral_constant<int, 0>{}, t + 1);
+            round(std::integral_constant<int, 1>{}, t + 2);
+            round(std::integral_constant<int, 2>{}, t + 3);
+        }
+        round(std::integral_constant<int, 3>{}, T4);
+        W2_CYC(0);
+        WS_LDS_BARRIER();
+        if (!RES && stats && T4 > 0) stats_collect(T4 - 1);
+        W2_CYC_OUT(1);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Round 4, what the wave-specialised forms measured (scripts/pws_bench.py, pws_pattern.py, pws2_cycles.py): four MFMA + four
+// output waves, eight + four and eight + eight all take the time of conv_pws_kernel, 94-96 us for 135,200 x 256 -> 1024
+// without statistics - while the SAME kernel on a 256 -> 256 layer with a residual (one cout tile: every block reads its
+// pixels once and writes whole rows) moves 5.1 TB/s.  What the four cout-tile blocks of a pixel tile have in common is the
+// activation tile: each of them pulls it through its own CU's vector-memory path (L2 hits, but 277 MB of LDS-DMA per call
+// beside 277 MB of stores), and the CUs together move ~5.5 TB/s whatever the source.  So: fewer passes of X.  A block here
+// holds the weights of 512 couts - eight waves x 64 couts x 256 channels = 128 VGPRs each, 256 KiB of registers, half the
+// CU's file - and X makes two passes instead of four.  Every wave does everything (LDS-DMA, MFMA, staging, read-back,
+// stores, statistics), in phases separated by two LDS-only barriers per 32-pixel sub-tile; scheduling unit and BN statistic
+// row = 64 pixels (two sub-tiles), so 128 sequences share the 2,113 units of a 32-image batch 17 : 16.
+constexpr int P3_SUB = 32;
+constexpr int P3_XSLOT = P3_SUB * WS_ROWB;          // 16 KiB: [32 px][256 ch]
+constexpr int P3_XS = 4;
+constexpr int P3_SROW = 512 * 2;                    // staged output rows: 512 couts
+constexpr int P3_STAGE = P3_SUB * P3_SROW;          // 32 KiB
+constexpr int P3_RED = P3_XS * P3_XSLOT + P3_STAGE; // [8 waves][2][512] floats
+constexpr int P3_LDS = P3_RED + 8 * 2 * 512 * 4 + 16;
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv_pws3_kernel(ConvP p) {
+    typedef bf16_t T;
+    typedef Mma<T>::Frag Frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __shared__ __attribute__((aligned(16))) char smem[P3_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr_ = lane & 31, fh_ = lane >> 5, fx_ = fr_ & 15;
+#ifdef EESEG_W2_WHATIF    // what-if switches of a diagnostic build (EESEG_W2_VAR): each leaves one piece of a round out
+    const int var = p.tap_inner;
+#else
+    constexpr int var = 0;
+#endif
+    // block -> (512-cout tile, unit sequence): the blocks that walk the same pixels at the same time share an XCD (blockIdx % 8)
+    const int per = 8 * p.n_tiles;                               // n_tiles = Cout / 512 here
+    const int grp = blockIdx.x / per, g = blockIdx.x % per;
+    const int nt = g >> 3, seq = grp * 8 + (g & 7), nseq = (gridDim.x / per) * 8;
+    const int n0 = nt * 512;
+    const int n_u = p.m_tiles;                                   // 64-pixel units (= BN statistic rows of this kernel)
+    const int T2 = seq < n_u ? 2 * ((n_u - seq + nseq - 1) / nseq) : 0;   // sub-tiles of this block
+    auto row0 = [&](int t) { return (seq + (t >> 1) * nseq) * 64 + (t & 1) * P3_SUB; };
+    char* const sS = smem + P3_XS * P3_XSLOT;
+    float* const sRed = reinterpret_cast<float*>(smem + P3_RED);
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
+    const uint32_t ybytes = (uint32_t)(((size_t)(p.M - 1) * p.ldy + p.Cout) * 2);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, ybytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(RES ? p.residual : p.y, RES ? (uint32_t)(((size_t)(p.M - 1) * p.ldres + p.Cout) * 2) : ybytes);
+    // LDS-DMA: one wave instruction = 2 rows x 512 B; instruction q of wave w covers rows (w*2+q)*2 + (lane>>5) of the sub-tile
+    auto issue = [&](int t) {
+        int drow = lane >> 5, dslot = lane & 31;
+        asm volatile("" : "+v"(drow), "+v"(dslot));              // recomputed per call: no hoisted addresses beside the weights
+        char* sx = smem + (t & 3) * P3_XSLOT;
+        const int mb = row0(t);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wave * 2 + q) * 2 + drow;
+            const int m = mb + r;
+            const uint32_t voff = (t < T2 && m < p.M && !(var & 32)) ? (uint32_t)(m * WS_ROWB + ((dslot ^ (r & 15)) << 4)) : EESEG_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16, (int)voff, 0, 0, 0);
+        }
+    };
+    Frag a[2][16];                                                // this wave's 64 couts, all of K, as A fragments
+    {
+        const T* w = reinterpret_cast<const T*>(p.w);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* wr = w + (size_t)(n0 + wave * 64 + i * 32 + fr_) * WS_K + fh_ * 8;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(wr + ks * 16);
+        }
+    }
+    // the weights are awaited HERE, by waits the compiler places itself (an empty asm that reads every fragment): its wait-count pass
+    // does not read the counted waits in the inline assembly below and would otherwise keep waiting for "possibly outstanding" weights
+    // inside every round's MFMAs - each such wait also drains the LDS-DMA just issued
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" :: "v"(a[i][ks]));
+    asm volatile("" ::: "memory");
+    issue(0);
+    issue(1);
+    issue(2);
+    float* const stats = RES ? nullptr : p.stats;
+    f32x2 a1[4], a2[4];
+    // the sums of a finished unit cross the eight waves through sRed and are stored one round later (behind that round's barrier)
+    auto stats_collect = [&](int t_done) {                       // t_done: last sub-tile of the unit (odd)
+        const int col = tid;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += sRed[(w8 * 2 + which) * 512 + col];
+            stats[((size_t)(seq + (t_done >> 1) * nseq) * 2 + which) * p.Cout + n0 + col] = s;
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < T2; ++t) {
+        // vector-memory operations retire in order; behind the LDS-DMA of sub-tile t (issued in round t - 3) this wave has issued at
+        // least: the stores of round t - 3 (4), and the residual requests (4 + 4 mask bytes), LDS-DMA (2) and stores (4) of rounds
+        // t - 2 and t - 1 - every one of them unconditionally (rows past the end go out of range, not away).  The statistics stores
+        // of every other round are not counted: waiting for a few operations more than needed is safe, for fewer is not.
+        // (The residual is requested BEFORE the round's LDS-DMA: its data cannot return before everything older has, and behind the
+        // DMA it would pull sub-tile t + 3 in within this round.)
+        // (the first three rounds have fewer behind theirs: they wait for everything)
+        if (t < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (!RES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (p.resmask) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        WS_LDS_BARRIER();                                         // X(t) is there for every wave; the staging area and sRed have been read
+        if (!RES && stats && t >= 2 && (t & 1) == 0) stats_collect(t - 1);
+        int fr = fr_, fh = fh_, fx = fx_, c = tid & 63, r0 = wave;
+        asm volatile("" : "+v"(fr), "+v"(fh), "+v"(fx), "+v"(c));
+        const int mh = row0(t);
+        const int cg = n0 + c * 8;
+        i32x4 rr[4];
+        unsigned mb[4];
+        if (RES) {                                                // requested now, used behind the MFMAs
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = mh + r0 + 8 * it;
+                const uint32_t off = m < p.M ? (uint32_t)(((size_t)m * p.ldres + cg) * 2) : EESEG_OOB;
+                rr[it] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0);
+                const int mc = m < p.M ? m : p.M - 1;
+                mb[it] = p.resmask ? p.resmask[(size_t)mc * p.ldmask + (cg >> 3)] : 0xffu;
+            }
+            asm volatile("" ::: "memory");
+        }
+        issue(t + 3);                                             // into the slot round t - 1 consumed (zero-fill past the end)
+        asm volatile("" ::: "memory");
+        {
+            const char* r = smem + (t & 3) * P3_XSLOT + fr * WS_ROWB;
+            f32x16 acc[2];
+            Frag b[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[0][u] = *reinterpret_cast<const Frag*>(r + (((u * 2 + fh) ^ fx) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {                      // 2 k-steps at a time, the next pair's fragments requested first
+                if (kk < 7) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        b[(kk + 1) & 1][u] = *reinterpret_cast<const Frag*>(r + (((((kk + 1) * 2 + u) * 2 + fh) ^ fx) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if (kk == 0 && u == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0][0], z, 0, 0, 0);
+                        } else {
+                            Mma<T>::run(a[i][kk * 2 + u], b[kk & 1][u], acc[i]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // stage [px][512 couts] as bf16 (16-byte chunks XOR-ed with px & 15: the 1-KiB pitch maps every row to the same banks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    T v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = from_f32<T>(acc[i][4 * gq + e]);
+                    const int cl = wave * 64 + i * 32 + 8 * gq + 4 * fh;
+                    *reinterpret_cast<bf16x4*>(sS + fr * P3_SROW + ((((cl >> 3) ^ fx) << 4) | ((cl & 4) << 1))) = bf16x4{v[0], v[1], v[2], v[3]};
+                }
+        }
+        WS_LDS_BARRIER();
+        // ---- read back 4 rows x 16 B per thread (thread = chunk c of rows wave + 8*it), residual, ReLU, store, BN partial sums ----
+        i32x4 rq[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = r0 + 8 * it;
+            rq[it] = *reinterpret_cast<const i32x4*>(sS + row * P3_SROW + ((c ^ (row & 15)) << 4));
+        }
+        if ((t & 1) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a1[k] = f32x2{0.f, 0.f}; a2[k] = f32x2{0.f, 0.f}; }
+        }
+        if (RES || p.relu) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                union { i32x4 q; T e[8]; } v, vr;
+                v.q = rq[it];
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = to_f32(v.e[e]);
+                if (RES) {
+                    vr.q = p.resmask ? mask_chunk_bf16(rr[it], mb[it]) : rr[it];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = to_f32(from_f32<T>(f[e] + to_f32(vr.e[e])));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.e[e] = from_f32<T>(f[e]);
+                rq[it] = v.q;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int m = mh + r0 + 8 * it;
+            uint32_t off = m < p.M ? (uint32_t)(((size_t)m * p.ldy + cg) * 2) : EESEG_OOB;
+            if (var & 128) off = m < p.M ? (uint32_t)((((size_t)nt * p.M + m) * 512 + c * 8) * 2) : EESEG_OOB;   // every block a stream of its own
+            if (var & 4) off = EESEG_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(rq[it], ry, (int)off, 0, 0);
+        }
+        if (!RES && stats && !(var & 2)) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (mh + r0 + 8 * it < p.M) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned w = (unsigned)rq[it][k];
+                        const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                        a1[k] += f;
+                        a2[k] += f * f;
+                    }
+                }
+            }
+            if (t & 1) {                                          // the unit is complete: this wave's sums of its 8 rows go to sRed
+                f32x4* d1 = reinterpret_cast<f32x4*>(sRed + (wave * 2 + 0) * 512 + c * 8);
+                f32x4* d2 = reinterpret_cast<f32x4*>(sRed + (wave * 2 + 1) * 512 + c * 8);
+                d1[0] = f32x4{a1[0][0], a1[0][1], a1[1][0], a1[1][1]};
+                d1[1] = f32x4{a1[2][0], a1[2][1], a1[3][0], a1[3][1]};
+                d2[0] = f32x4{a2[0][0], a2[0][1], a2[1][0], a2[1][1]};
+                d2[1] = f32x4{a2[2][0], a2[2][1], a2[3][0], a2[3][1]};
+            }
+        }
+    }
+    WS_LDS_BARRIER();
+    if (!RES && stats && T2 > 0) stats_collect(T2 - 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // trailing out-of-range DMAs still write into LDS
+}
+
 int g_conv_pw_all = 0;        // EESEG_OPT_CONV_PW_ALL: 1 = every eligible pointwise layer on conv_pw_kernel, not only the output-heavy ones
 int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwise layers on the weight-stationary kernel
 
@@ -2250,7 +2793,7 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_pw_all = value;
         return EESEG_OK;
     }
-    if (key == EESEG_OPT_CONV_PWS && (value == 0 || value == 1)) {
+    if (key == EESEG_OPT_CONV_PWS && value >= 0 && value <= 5) {
         g_conv_pws = value;
         return EESEG_OK;
     }
@@ -2396,7 +2939,42 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
-            if (a->residual) hipLaunchKernelGGL(conv_pws_kernel<true>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
+            if (g_conv_pws == 5 && a->Cout % 512 == 0 && (long long)M * a->ldy * 2 < (1ll << 31) &&
+                (!a->residual || (long long)M * a->ldres * 2 < (1ll << 31))) {
+                // 512 couts per block, every wave in every role: X makes Cout / 512 passes through the CUs instead of Cout / 256
+                p.n_tiles = a->Cout / 512;
+                p.m_tiles = (M + 63) / 64;                                    // 64-pixel units = statistic rows of this kernel
+#ifdef EESEG_W2_WHATIF
+                p.tap_inner = getenv("EESEG_W2_VAR") ? atoi(getenv("EESEG_W2_VAR")) : 0;
+#endif
+                const int per5 = 8 * p.n_tiles;
+                int groups5 = g_conv_big_cus / per5;
+                if (groups5 < 1) groups5 = 1;
+                while (groups5 > 1 && (groups5 - 1) * 8 >= p.m_tiles) --groups5;
+                if (a->residual) hipLaunchKernelGGL(conv_pws3_kernel<true>, dim3((unsigned)(groups5 * per5)), dim3(512), 0, st, p);
+                else hipLaunchKernelGGL(conv_pws3_kernel<false>, dim3((unsigned)(groups5 * per5)), dim3(512), 0, st, p);
+                g_last_conv_kernel = EESEG_KERNEL_CONV_PWS;
+                g_last_stats_rows = p.m_tiles;
+                EESEG_LAUNCH_CHECK();
+                return EESEG_OK;
+            }
+            if (g_conv_pws >= 2) {                                            // wave-specialised forms: one block per CU
+#ifdef EESEG_W2_WHATIF
+                p.tap_inner = getenv("EESEG_W2_VAR") ? atoi(getenv("EESEG_W2_VAR")) : 0;
+#endif
+                groups = g_conv_big_cus / per;
+                if (groups < 1) groups = 1;
+                while (groups > 1 && (groups - 1) * 8 >= p.m_tiles) --groups;
+                const dim3 grid2((unsigned)(groups * per));
+                if (g_conv_pws == 4) {                                        // eight MFMA waves of 32 couts + eight output waves
+                    if (a->residual) hipLaunchKernelGGL((conv_pws2_kernel<true, 8, 8>), grid2, dim3(1024), 0, st, p);
+                    else hipLaunchKernelGGL((conv_pws2_kernel<false, 8, 8>), grid2, dim3(1024), 0, st, p);
+                } else if (g_conv_pws == 3) {                                 // eight MFMA waves of 32 couts (two per SIMD) + four output waves
+                    if (a->residual) hipLaunchKernelGGL((conv_pws2_kernel<true, 8, 4>), grid2, dim3(768), 0, st, p);
+                    else hipLaunchKernelGGL((conv_pws2_kernel<false, 8, 4>), grid2, dim3(768), 0, st, p);
+                } else if (a->residual) hipLaunchKernelGGL((conv_pws2_kernel<true, 4, 4>), grid2, dim3(512), 0, st, p);
+                else hipLaunchKernelGGL((conv_pws2_kernel<false, 4, 4>), grid2, dim3(512), 0, st, p);
+            } else if (a->residual) hipLaunchKernelGGL(conv_pws_kernel<true>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
             else hipLaunchKernelGGL(conv_pws_kernel<false>, dim3((unsigned)(groups * per)), dim3(256), 0, st, p);
             g_last_conv_kernel = EESEG_KERNEL_CONV_PWS;
             g_last_stats_rows = p.m_tiles;

@@ -363,3 +363,52 @@ def test_lovasz_class_shares_add_up_to_the_whole_loss(classes):
         ds_sh[:, own] = d_r
     assert abs(total - float(loss.item())) <= 2e-6 * abs(float(loss.item())), (total, float(loss.item()))
     assert torch.equal(ds_sh, ds)
+
+
+# ---- wave-specialised weight-stationary pointwise kernel (conv_pws2_kernel, EESEG_OPT_CONV_PWS = 2) ----
+
+@pytest.mark.parametrize("shape", [(16, 65, 65), (17, 64, 67), (32, 65, 65)], ids=str)
+def test_wave_specialised_pointwise_is_bit_identical_to_the_single_role_kernel(shape):
+    """256 -> 1024 expanding pointwise conv and the 1024 -> 256 data-gradient that adds a masked residual: the kernel with
+    MFMA waves and output waves (option 14 = 2: four MFMA waves of 64 couts, 3: eight of 32, 4: eight of 32 and eight output waves; 5: 512 couts per block,
+    every wave in every role) issues the same MFMAs in the same order and sums the BN partial statistics
+    in the same order as conv_pws_kernel (option 14 = 1) - outputs AND statistics must be equal bit for bit; both against
+    torch.  Ragged pixel counts: the last 128-pixel tile is partial, the tile count is not a multiple of the sequences."""
+    from ee_semantic_segmentation_amd._lib import lib
+    N, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, 256, generator=g).to(DEV).bfloat16()
+    wt = (torch.randn(1024, 256, 1, 1, generator=g) * 256 ** -0.5).to(DEV)
+    wf, _ = K.pack_weight(wt, torch.bfloat16)
+    dy = torch.randn(N, H, W, 256, generator=g).to(DEV).bfloat16()
+    wt2 = (torch.randn(256, 1024, 1, 1, generator=g) * 0.05).to(DEV)          # forward conv 1024 -> 256: its dgrad expands
+    _, wb2 = K.pack_weight(wt2, torch.bfloat16)
+    c = torch.randn(N, H, W, 1024, generator=g).to(DEV).bfloat16()
+    ss = torch.stack([torch.rand(1024, generator=g) + 0.5, torch.randn(1024, generator=g) * 0.1]).to(DEV)
+    yb, mask = K.bn_apply(c, ss, relu=True, want_mask=True)
+    t = torch.randn(N, H, W, 1024, generator=g).to(DEV).bfloat16()
+    got = {}
+    for mode in (1, 2, 3, 4, 5):
+        assert lib().eeseg_set_option(14, mode) == 0
+        try:
+            y, part = K.conv_fwd(x, wf, want_stats=True)
+            assert lib().eeseg_last_kernel(0) == 5
+            yr, _ = K.conv_fwd(x, wf, relu=True)
+            dx = K.conv_dgrad(dy, wb2, (H, W), add=(t, mask))
+            dx2 = K.conv_dgrad(dy, wb2, (H, W), accumulate_into=t.clone())
+            got[mode] = (y, part.clone(), yr, dx, dx2)
+        finally:
+            lib().eeseg_set_option(14, 1)
+    for mode in (2, 3, 4, 5):
+        for a, b, what in zip(got[1], got[mode], ("output", "statistics", "relu output", "dgrad + masked residual", "dgrad accumulate")):
+            if mode >= 4 and what == "statistics":       # other rows per thread (mode 5: one row of sums per 64 pixels): another order of the sums
+                assert torch.allclose(K.reduce_partials(a), K.reduce_partials(b), rtol=1e-5, atol=1e-3)
+            else:
+                assert torch.equal(a, b), (mode, what)
+    want = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wt.bfloat16().float()).permute(0, 2, 3, 1)
+    assert float((got[2][0].float() - want).abs().max()) < 0.06
+    sums = K.reduce_partials(got[2][1])
+    ys = got[2][0].float().reshape(-1, 1024)
+    assert torch.allclose(sums[0], ys.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(sums[1], (ys * ys).sum(0), rtol=1e-4, atol=1e-2)
+    wantd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wt2.bfloat16().float()).permute(0, 2, 3, 1)
+    assert float((got[2][3].float() - (wantd + t.float() * (yb > 0))).abs().max()) < 0.06
