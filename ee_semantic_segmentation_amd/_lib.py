@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EESEG_LIB: another build of the SAME ABI (same-box A/B of two builds); default = the in-tree library.  lib() refuses a
 # library whose eeseg_version() differs from ABI_VERSION: the ctypes signatures below are written for exactly that ABI
 LIB_PATH = os.environ.get("EESEG_LIB") or os.path.join(_HERE, "libeeseg.so")
-ABI_VERSION = 104      # bumped with every signature / struct change of include/eeseg.h (csrc/api.hip returns the same number)
+ABI_VERSION = 105      # bumped with every signature / struct change of include/eeseg.h (csrc/api.hip returns the same number)
 
 F32, BF16 = 0, 1
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "eeseg_conv_igemm": (_i, [C.POINTER(ConvArgs), _vp]),
     "eeseg_conv_workspace": (_i64, []),
     "eeseg_conv_wgrad": (_i, [C.POINTER(WgradArgs), _vp]),
+    "eeseg_conv_wgrad_group": (_i, [C.POINTER(WgradArgs), _i, _vp]),
+    "eeseg_set_wgrad_group": (_i, [_i]),
     "eeseg_wgrad_workspace": (_i64, []),
     "eeseg_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "eeseg_pack_weight_multi": (_i, [_vp, _i, _i, _vp]),

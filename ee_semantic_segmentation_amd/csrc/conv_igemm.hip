@@ -2708,11 +2708,13 @@ extern int g_bn_nt;
 extern int g_colreduce_blocks;
 
 extern int g_last_wgrad_kernel;   // conv_wgrad.hip
+extern int g_last_wgrad_group;
 
 extern "C" int eeseg_last_kernel(int which) {
     if (which == 0) return g_last_conv_kernel;
     if (which == 1) return g_last_wgrad_kernel;
     if (which == 2) return g_last_stats_rows;
+    if (which == 3) return g_last_wgrad_group;
     return EESEG_ERR_ARG;
 }
 

@@ -10,6 +10,7 @@
 #include "eeseg_common.h"
 
 int g_last_wgrad_kernel = 0;        // eeseg_last_kernel(1) (conv_igemm.hip)
+int g_last_wgrad_group = 0;         // eeseg_last_kernel(3): problems the last eeseg_conv_wgrad_group call put into ONE launch (0 = it launched them one by one)
 
 namespace {
 
@@ -358,14 +359,17 @@ template <bool M16> __device__ __forceinline__ int wg_sub_ci(int g, int lane) {
 // read block is 4 pixel rows x 16 channels per 16-lane group either way; the 16x16 operand wants pixels 8g .. 8g+7 of a 32-pixel
 // K step in group g = lane >> 4 (all four groups the same 16 channels), so lanes 0-31 touch rows {tq, 8 + tq} x 32 bytes: the
 // source-chunk swizzle gains a 32-byte XOR on row bit 3 to keep those on different banks.
+// The body serves two kernels: one weight gradient per launch (vbid / vgrid = blockIdx.x / gridDim.x), and - round 4, the
+// per-GPU shards of a data-parallel run - several weight gradients side by side in ONE launch (conv_wgrad_group_kernel:
+// vbid / vgrid = the block's index / block count within its own problem, group0 = first barrier group of the problem).
 template <bool FAST, bool M16>
-__global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
+__device__ __forceinline__ void wgrad_big_body(const WgP& p, const int vbid, const int vgrid, const unsigned group0) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef __attribute__((address_space(3))) s16x4* lds_tr;
     __shared__ __attribute__((aligned(16))) char smem[WB_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int taps = p.R * p.S;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(vbid, vgrid);
     const int unit = bid;                      // = ((split * taps + tap) * ci_tiles + ci_t) * co_tiles + co_t
     const int co_t = bid % p.co_tiles; bid /= p.co_tiles;
     const int ci_t = bid % p.ci_tiles; bid /= p.ci_tiles;
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
                         __builtin_amdgcn_raw_buffer_store_b128(u.q, rs, (int)(off + (uint32_t)(((i * 4 + j) * 4 + g) * 1024)), 0, 16);   // aux 16 = sc1
                     }
         }
-        eeseg_group_barrier(p.bstate, (unsigned)tl, (unsigned)p.splits);
+        eeseg_group_barrier(p.bstate, group0 + (unsigned)tl, (unsigned)p.splits);
         const int lo = (int)((long long)split * 16384 / p.splits), hi = (int)((long long)(split + 1) * 16384 / p.splits);
         const int co_t2 = tl % p.co_tiles, ci_t2 = (tl / p.co_tiles) % p.ci_tiles;      // (= co_t, ci_t of this block)
         for (int idx = lo + tid; idx < hi; idx += 512) {
@@ -860,6 +864,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
     }
 }
 
+template <bool FAST, bool M16>
+__global__ __launch_bounds__(512) void conv_wgrad_big_kernel(WgP p) {
+    wgrad_big_body<FAST, M16>(p, (int)blockIdx.x, (int)gridDim.x, 0u);
+}
+
+// Several weight gradients in one launch (in-kernel combine only: every block resident).  At a per-GPU shard of a few images a
+// single weight gradient has too little K for the chip: 4-9 output tiles x 264 K tiles split 64 ways leave ~4 K tiles per block
+// and a combine of 64 slabs per tile (32 us per call whatever the block count, scripts/wgrad_group_probe.py); the three
+// gradients of a bottleneck block side by side get ~15 splits each: 4x the K per block, a quarter of the combine traffic, one launch.
+constexpr int WG_GROUP_MAX = 4;
+struct WgGroup {
+    WgP p[WG_GROUP_MAX];
+    int start[WG_GROUP_MAX + 1];      // first block of problem i (start[n] = grid)
+    unsigned group0[WG_GROUP_MAX];    // first barrier group (= output tile) of problem i
+    int n;
+};
+template <bool FAST, bool M16>
+__global__ __launch_bounds__(512) void conv_wgrad_group_kernel(WgGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    wgrad_big_body<FAST, M16>(g.p[i], (int)blockIdx.x - g.start[i], g.start[i + 1] - g.start[i], g.group0[i]);
+}
+
 // dW[co][tap][ci] += sum over the K splits of one 256x256 tile, slabs in the producing kernel's register layout.
 // grid = (tiles x 8, G): one block per producing wave (= 32 KiB of every slab) and per group of splits, 256 threads.
 // G > 1 (few output tiles, many splits: tiles x 8 blocks alone would read the slabs at a fraction of the memory rate):
@@ -918,6 +945,7 @@ int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this 
 int g_wgrad_m16 = 0;                // eeseg_set_wgrad_big(on | 16): 256x256 kernel on v_mfma_f32_16x16x32_bf16
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
 int g_wgrad_coop = 1;               // eeseg_set_wgrad_big(on | 8): 8 (default) = combine the K splits INSIDE the kernel when its whole grid is resident
+int g_wgrad_group_max_ktiles = 640;  // eeseg_set_wgrad_group(n): weight gradients of at most this many 64-pixel K tiles are grouped (0 = never); 640 = 9 images of 65 x 65
 int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_target_blocks); 0 = by the cost model below
 
 // Cost model of the 128x128-tile kernel (fitted to scripts/wgrad_sweep.py, MI355X, us): a block takes ~1.0 us per
@@ -1135,6 +1163,102 @@ extern "C" int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream) {
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<float>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_set_wgrad_group(int max_ktiles) {
+    EESEG_CHECK(max_ktiles >= 0 && max_ktiles <= (1 << 20), EESEG_ERR_ARG, "set_wgrad_group: out of range");
+    g_wgrad_group_max_ktiles = max_ktiles;
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_conv_wgrad_group(const eeseg_wgrad_args* a, int n, void* stream) {
+    EESEG_CHECK(a && n >= 1 && n <= WG_GROUP_MAX, EESEG_ERR_ARG, "conv_wgrad_group: 1 .. %d problems", WG_GROUP_MAX);
+    g_last_wgrad_group = 0;
+    extern int eeseg_get_option(int);
+    const long long T = eeseg_get_option(EESEG_OPT_CONV_CUS);
+    // one launch only if EVERY problem is one the 256x256 kernel combines in-kernel, all of them small (few K tiles) and of one kernel
+    // instantiation; anything else: the calls one by one, each with its own plan
+    bool ok = n >= 2 && g_wgrad_big && g_wgrad_coop && g_wgrad_group_max_ktiles > 0 && g_wgrad_target_blocks == 0;
+    long long tiles[WG_GROUP_MAX], kt[WG_GROUP_MAX], sum_tiles = 0;
+    double work = 0.0;
+    for (int i = 0; ok && i < n; ++i) {
+        const eeseg_wgrad_args& q = a[i];
+        ok = q.x && q.dy && q.dw && q.dtype == EESEG_BF16 && q.Cout % 256 == 0 && q.Cin % 256 == 0 && q.N > 0 && q.Hout > 0 && q.Wout > 0 &&
+             q.R * q.S >= 1 && q.stride >= 1 && q.dil >= 1 && 64 / q.Wout + 1 <= q.Hout && (64 / q.Wout == 0) == (64 / a[0].Wout == 0) &&
+             q.workspace == a[0].workspace && q.workspace_bytes == a[0].workspace_bytes && q.barrier_state == a[0].barrier_state &&
+             q.workspace && q.barrier_state && ((uintptr_t)q.barrier_state & 127) == 0 &&
+             ((uintptr_t)q.x & 15) == 0 && ((uintptr_t)q.dy & 15) == 0 && ((uintptr_t)q.dw & 3) == 0;
+        if (!ok) break;
+        const long long M = (long long)q.N * q.Hout * q.Wout;
+        ok = (long long)q.N * q.Hin * q.Win * q.Cin * 2 < (1ll << 31) && M * q.Cout * 2 < (1ll << 31);
+        tiles[i] = (long long)(q.Cout / 256) * (q.Cin / 256) * q.R * q.S;
+        kt[i] = (M + 63) / 64;
+        ok = ok && kt[i] <= g_wgrad_group_max_ktiles;
+        sum_tiles += tiles[i];
+        work += (double)tiles[i] * (double)kt[i];
+    }
+    ok = ok && sum_tiles <= T && sum_tiles <= EESEG_BARRIER_GROUPS;
+    WgGroup g;
+    long long blocks = 0, slab_tiles = 0;
+    if (ok) {
+        g.n = n;
+        for (int i = 0; i < n; ++i) {
+            const eeseg_wgrad_args& q = a[i];
+            const long long M = (long long)q.N * q.Hout * q.Wout;
+            // blocks in proportion to the MFMA work, whole splits of the problem's tiles
+            long long sp = (long long)((double)T * ((double)tiles[i] * (double)kt[i] / work)) / tiles[i];
+            const long long max_sp = (kt[i] + 3) / 4;                       // at least 4 K tiles per block
+            if (sp > max_sp) sp = max_sp;
+            if (sp < 1) sp = 1;
+            long long chunk = (M + sp - 1) / sp;
+            chunk = (chunk + 63) / 64 * 64;
+            sp = (M + chunk - 1) / chunk;
+            WgP& p = g.p[i];
+            p.x = q.x; p.dy = q.dy; p.dw = q.dw;
+            p.N = q.N; p.Hin = q.Hin; p.Win = q.Win; p.Cin = q.Cin;
+            p.Hout = q.Hout; p.Wout = q.Wout; p.Cout = q.Cout; p.R = q.R; p.S = q.S;
+            p.stride = q.stride; p.pad = q.pad; p.dil = q.dil; p.lddy = q.Cout;
+            p.M = (int)M; p.HWout = q.Hout * q.Wout;
+            p.co_tiles = q.Cout / 256; p.ci_tiles = q.Cin / 256;
+            p.xbytes = (uint32_t)((long long)q.N * q.Hin * q.Win * q.Cin * 2); p.dybytes = (uint32_t)(M * q.Cout * 2);
+            p.q64 = 64 / q.Wout; p.r64 = 64 % q.Wout;
+            p.qk = 64 / q.Wout; p.rk = 64 % q.Wout; p.fast_wrap = (p.qk + 1 <= q.Hout) ? 1 : 0;
+            p.splits = (int)sp; p.chunk = (int)chunk;
+            p.slabs = reinterpret_cast<float*>(q.workspace) + (size_t)slab_tiles * 65536;
+            p.bstate = reinterpret_cast<unsigned*>(q.barrier_state);
+            g.start[i] = (int)blocks;
+            g.group0[i] = (unsigned)(i == 0 ? 0 : g.group0[i - 1] + (unsigned)tiles[i - 1]);
+            blocks += tiles[i] * sp;
+            slab_tiles += tiles[i] * sp;
+        }
+        for (int i = n; i <= WG_GROUP_MAX; ++i) g.start[i] = (int)blocks;
+        ok = blocks <= T && slab_tiles * 262144ll <= a[0].workspace_bytes;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = eeseg_conv_wgrad(&a[i], stream);
+            if (rc != EESEG_OK) return rc;
+        }
+        g_last_wgrad_group = 0;
+        return EESEG_OK;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i)
+        if (!a[i].accumulate)
+            EESEG_HIP(hipMemsetAsync(a[i].dw, 0, (size_t)a[i].Cout * a[i].R * a[i].S * a[i].Cin * sizeof(float), st));
+    const bool m16 = g_wgrad_m16 != 0;
+    const dim3 grid((unsigned)blocks);
+    if (g.p[0].q64 == 0) {
+        if (m16) hipLaunchKernelGGL((conv_wgrad_group_kernel<true, true>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_group_kernel<true, false>), grid, dim3(512), 0, st, g);
+    } else {
+        if (m16) hipLaunchKernelGGL((conv_wgrad_group_kernel<false, true>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgrad_group_kernel<false, false>), grid, dim3(512), 0, st, g);
+    }
+    g_last_wgrad_kernel = EESEG_KERNEL_WGRAD_BIG;
+    g_last_wgrad_group = n;
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

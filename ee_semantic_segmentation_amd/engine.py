@@ -53,6 +53,11 @@ class Config:
         # 4 images), and no run with more than one rank has executed it; default = collective on the compute stream, weight
         # gradient in place.
         self.defer_wgrad = __import__("os").environ.get("EESEG_DEFER_WGRAD", "0") == "1"
+        # round 4: the weight gradients of a unit (the three convs of a bottleneck block) are queued and issued as ONE launch where the
+        # library can put them side by side (eeseg_conv_wgrad_group: per-GPU shards of a few images; bigger batches are issued one by
+        # one, just later) - arena mode only (the kernel writes the gradient in place, nothing to hand back to autograd)
+        self.group_wgrad = __import__("os").environ.get("EESEG_GROUP_WGRAD", "1") == "1"
+        self._wgrad_queue = []
         self._deferred = None
         self.comm = None                     # comm.DataParallelComm: RCCL through libeeseg (parallel.init_data_parallel)
 
@@ -145,16 +150,29 @@ class Config:
     def reset_transients(self):
         """Drop everything a failed / abandoned step may have left behind (held-back weight gradient, side-stream state)."""
         self._deferred = None
+        self._wgrad_queue = []
         self._side_busy = False
         self._side_keep = []
         if self.comm is not None:
             self.comm.lane_g.busy = self.comm.lane_s.busy = False
 
     def run_deferred(self):
-        """Issue the weight gradient that conv_bn_bwd held back (no-op when there is none)."""
+        """Issue the weight gradient(s) that conv_bn_bwd held back (no-op when there is none)."""
         fn, self._deferred = self._deferred, None
         if fn is not None:
             fn()
+        self.flush_wgrads()
+
+    def queue_wgrad(self, item):
+        """item = (x, dy, R, S, stride, pad, dil, out, accumulate) of kernels.conv_wgrad_group; the queue keeps x and dy alive."""
+        self._wgrad_queue.append(item)
+        if len(self._wgrad_queue) == 4:
+            self.flush_wgrads()
+
+    def flush_wgrads(self):
+        q, self._wgrad_queue = self._wgrad_queue, []
+        if q:
+            K.conv_wgrad_group(q)
 
     def next_seed(self):
         self._drop_calls += 1
@@ -606,7 +624,11 @@ def conv_bn_bwd(cfg, st, dy, conv, bn, need_dx=True, dx_accum=None, want_dres=Fa
         cfg._deferred = wgrad                # the closure keeps x and dc alive
         dwp = None
     else:
-        dwp = wgrad()
+        if gv is not None and cfg.group_wgrad and dc.is_cuda:
+            cfg.queue_wgrad((x, dc, R, S, s, p, d, gv, cfg.accumulate or cfg.arena.prezeroed))     # issued with the unit's others
+            dwp = None
+        else:
+            dwp = wgrad()
         if need_dx:
             _, wb = packed(conv, dc.dtype)
             dx = K.conv_dgrad(dc, wb, (x.shape[1], x.shape[2]), s, p, d, accumulate_into=dx_accum, add=dx_add)

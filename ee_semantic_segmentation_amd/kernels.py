@@ -354,6 +354,39 @@ def conv_wgrad(x, dy, R, S, stride=1, pad=0, dil=1, *, out=None, accumulate=Fals
     return out
 
 
+def _wgrad_args(a, x, dy, R, S, stride, pad, dil, out, accumulate):
+    N, H, W, Cin = x.shape
+    N2, Ho, Wo, Cout = dy.shape
+    assert N2 == N and x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype
+    assert out.is_contiguous() and out.numel() == Cout * R * S * Cin and out.dtype == torch.float32
+    a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
+    a.N, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.R, a.S = N, H, W, Cin, Ho, Wo, Cout, R, S
+    a.stride, a.pad, a.dil, a.dtype, a.accumulate = stride, pad, dil, _dt(x), int(accumulate)
+    if (WGRAD_SLABS or WGRAD_COOP) and a.dtype == BF16 and Cout % 128 == 0 and Cin % 128 == 0:
+        ws = _wgrad_ws(x.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        if WGRAD_COOP:
+            a.barrier_state = coop_state(x.device, "wgrad").data_ptr()
+    return 2.0 * N * Ho * Wo * Cout * Cin * R * S, (2.0 if a.dtype == BF16 else 4.0) * (N * H * W * Cin + N * Ho * Wo * Cout) + 4.0 * Cout * R * S * Cin
+
+
+def conv_wgrad_group(items):
+    """The weight gradients of up to 4 convolutions in ONE launch where the library can (eeseg_conv_wgrad_group: small per-GPU
+    shards), else one by one.  items: [(x, dy, R, S, stride, pad, dil, out, accumulate)] - `out` fp32 KRSC, written / added in place."""
+    assert 1 <= len(items) <= 4
+    arr = (WgradArgs * len(items))()
+    flops = byts = 0.0
+    for a, it in zip(arr, items):
+        _need_cuda(it[0], it[1])
+        f, b = _wgrad_args(a, *it)
+        flops, byts = flops + f, byts + b
+    ev = _prof_begin()
+    check(lib().eeseg_conv_wgrad_group(arr, len(items), _stream()), "eeseg_conv_wgrad_group")
+    if ev is not None:
+        n = lib().eeseg_last_kernel(3)
+        _prof_end(ev, "conv_wgrad_group" if n else "conv_wgrad (group issued one by one)", flops, byts, f"wgrad group of {len(items)}")
+
+
 def pack_weight(w, dtype, cout_pad=None, want_fwd=True, want_bwd=True):
     """w: fp32 parameter [Cout,Cin,R,S] (torch default or channels_last strides).
     Returns (w_fwd [Cout_pad,R,S,Cin], w_bwd [Cin,R,S,Cout_pad]) in `dtype`."""

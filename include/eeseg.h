@@ -49,7 +49,7 @@ enum { EESEG_OPT_CONV_SMALL_M_DEEP = 23 /* 1 (default): a launch of the 128x256 
        EESEG_OPT_CONV_MFMA16 = 17 /* 256x256 conv kernel: 1 (default) = v_mfma_f32_16x16x32_bf16, 0 = v_mfma_f32_32x32x16_bf16 (same tile, same LDS image, same cycles per FLOP; the chip holds a higher clock on the 16x16 shape: 3-7 % faster) */,
        EESEG_OPT_CONV_COUT_GROUP = 16 /* 256x256 conv kernel, layers with more cout tiles than this: the 32 CUs of an XCD work on `value` cout tiles x 32/value pixel tiles at a time (1, 2, 4, 8; default 0 = all cout tiles of few pixel tiles; an A/B switch, measured neutral on the 8-cout-tile layers) */,
        EESEG_OPT_CONV_PW_ALL = 15 /* 1: every eligible pointwise bf16 layer (Cin <= EESEG_OPT_CONV_PW_MAX_K) on the 128x256 kernel; 0 (default): the rule in eeseg_conv_igemm */,
-       EESEG_OPT_CONV_PWS = 14 /* 1 (default): expanding pointwise bf16 layers with Cin = 256 run on the weight-stationary persistent kernel (weights in registers, only activations stream); 0 = the 128x256 kernel */,
+       EESEG_OPT_CONV_PWS = 14 /* 1 (default): expanding pointwise bf16 layers with Cin = 256 run on the weight-stationary persistent kernel (weights in registers, only activations stream); 0 = the 128x256 kernel; 2 / 3 / 4 = the same layer with MFMA waves and output waves (4 + 4, 8 + 4, 8 + 8 waves per block; 2 and 3 bit-identical to 1), 5 = 512 couts per block (Cout % 512 == 0; one statistics row per 64 pixels) - measured alternatives of round 4, all within 10 % of 1 */,
        EESEG_OPT_CONV_PW_MAX_K = 13 /* pointwise (1x1, stride 1) bf16 layers with Cout % 256 == 0 and Cin <= value run on the 128x256 two-blocks-per-CU kernel (default 1280; 0 = never) */,
        EESEG_OPT_CONV_SPLIT_MIN_K = 12 /* 256x256 conv kernel: K tiles per K range of a split tail tile, at least (default 4) */,
        EESEG_OPT_COLREDUCE_BLOCKS = 11 /* column reductions (BN backward sums, channel statistics): blocks aimed at in all (default 512); 0 = up to 1024 row blocks per column block */,
@@ -152,6 +152,17 @@ typedef struct {
 } eeseg_wgrad_args;
 int64_t eeseg_wgrad_workspace(void);
 int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
+/* Round 4: the weight gradients of up to 4 convolutions in ONE launch (the three convs of a bottleneck block).  Replaces the same
+ * autograd step as eeseg_conv_wgrad (torch's conv backward reached from from_deepv3_new.py:146-151), `n` times.  At a per-GPU shard of
+ * a few images one weight gradient has too little K to fill the chip - every call costs ~32 us whatever its block count; side by side
+ * each problem gets a share of the CUs in proportion to its work, ~4x the K per block, a quarter of the combine traffic.  Taken when
+ * EVERY problem qualifies for the 256x256 kernel's in-kernel combine (bf16, Cin and Cout multiples of 256, the same `workspace` and
+ * `barrier_state` in all of them, output width on the same side of 64) and has at most eeseg_set_wgrad_group() K tiles of 64 pixels
+ * (default 640 = 9 images of 65 x 65; 0 = never): otherwise - and that is not an error - the calls are issued one by one exactly as
+ * eeseg_conv_wgrad would.  eeseg_last_kernel(3) = problems the last call put into one launch (0 = one by one).  Results are bitwise
+ * reproducible; they differ from the single calls' in the last bits (another K split). */
+int eeseg_conv_wgrad_group(const eeseg_wgrad_args* a, int n, void* stream);
+int eeseg_set_wgrad_group(int max_ktiles);
 
 /* fp32 master weight -> compute-dtype KRSC (`w_fwd` [Cout_pad][R][S][Cin], may be
  * NULL) and transposed CRSK (`w_bwd` [Cin][R][S][Cout_pad], may be NULL; the

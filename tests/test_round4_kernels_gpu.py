@@ -412,3 +412,63 @@ def test_wave_specialised_pointwise_is_bit_identical_to_the_single_role_kernel(s
     assert torch.allclose(sums[0], ys.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(sums[1], (ys * ys).sum(0), rtol=1e-4, atol=1e-2)
     wantd = torch.nn.functional.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wt2.bfloat16().float()).permute(0, 2, 3, 1)
     assert float((got[2][3].float() - (wantd + t.float() * (yb > 0))).abs().max()) < 0.06
+
+
+# ---- several weight gradients in one launch (eeseg_conv_wgrad_group) ----
+
+def _wgrad_items(B, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for cin, cout, k, d in ((1024, 256, 1, 1), (256, 256, 3, 2), (256, 1024, 1, 1)):
+        x = torch.randn(B, H, W, cin, generator=g).to(DEV).bfloat16()
+        dy = torch.randn(B, H, W, cout, generator=g).to(DEV).bfloat16()
+        items.append((x, dy, k, k, 1, d * (k // 2), d))
+    return items
+
+
+@pytest.mark.parametrize("shape", [(4, 65, 65), (3, 33, 47), (8, 65, 65)], ids=str)
+def test_grouped_weight_gradients_match_the_single_calls(shape):
+    """The three weight gradients of a bottleneck block (1x1 1024->256, 3x3 dilated 256->256, 1x1 256->1024) in ONE launch
+    (eeseg_conv_wgrad_group) against three eeseg_conv_wgrad calls and against torch: same sums, another K split (fp32 rounding
+    only); two grouped calls are bitwise equal (in-kernel combine in split order, no atomics); accumulate adds in place."""
+    from ee_semantic_segmentation_amd._lib import lib
+    B, H, W = shape
+    items = _wgrad_items(B, H, W)
+    single = [K.conv_wgrad(x, dy, r, s, st, p, d) for x, dy, r, s, st, p, d in items]
+    outs = [torch.empty_like(o) for o in single]
+    K.conv_wgrad_group([it + (o, False) for it, o in zip(items, outs)])
+    assert lib().eeseg_last_kernel(3) == 3, "the three problems did not share a launch"
+    assert K.coop_timeouts() == 0
+    for o, ref, (x, dy, r, s, st, p, d) in zip(outs, single, items):
+        scale = float(ref.abs().max())
+        assert float((o - ref).abs().max()) < 2e-5 * scale + 1e-3
+        want = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (dy.shape[-1], x.shape[-1], r, s), dy.float().permute(0, 3, 1, 2),
+                                           stride=st, padding=p, dilation=d).permute(0, 2, 3, 1)
+        assert float((o - want).abs().max()) < 2e-3 * float(want.abs().max())
+    outs2 = [torch.empty_like(o) for o in single]
+    K.conv_wgrad_group([it + (o, False) for it, o in zip(items, outs2)])
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2)), "grouped weight gradients are not reproducible"
+    K.conv_wgrad_group([it + (o, True) for it, o in zip(items, outs2)])
+    for a, b in zip(outs, outs2):
+        assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-6)
+
+
+def test_weight_gradient_group_falls_back_to_single_calls():
+    """Problems that cannot share a launch (a batch too large for the grouping to pay, a layer the 256x256 kernel does not take) are
+    issued one by one - bitwise what eeseg_conv_wgrad gives - and eeseg_last_kernel(3) says so."""
+    from ee_semantic_segmentation_amd._lib import lib
+    items = _wgrad_items(12, 65, 65)                    # 793 K tiles of 64 pixels: above the default limit of 640
+    single = [K.conv_wgrad(x, dy, r, s, st, p, d) for x, dy, r, s, st, p, d in items]
+    outs = [torch.empty_like(o) for o in single]
+    K.conv_wgrad_group([it + (o, False) for it, o in zip(items, outs)])
+    assert lib().eeseg_last_kernel(3) == 0
+    assert all(torch.equal(a, b) for a, b in zip(outs, single))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 33, 33, 64, generator=g).to(DEV).bfloat16()
+    dy = torch.randn(2, 33, 33, 64, generator=g).to(DEV).bfloat16()
+    small = _wgrad_items(2, 33, 33)[:1] + [(x, dy, 3, 3, 1, 1, 1)]
+    single = [K.conv_wgrad(x_, dy_, r, s, st, p, d) for x_, dy_, r, s, st, p, d in small]
+    outs = [torch.empty_like(o) for o in single]
+    K.conv_wgrad_group([it + (o, False) for it, o in zip(small, outs)])
+    assert lib().eeseg_last_kernel(3) == 0
+    assert all(torch.allclose(a, b, rtol=1e-5, atol=1e-4) for a, b in zip(outs, single))    # (the 64-channel layer sums with atomics)
