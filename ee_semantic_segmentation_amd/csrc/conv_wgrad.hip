@@ -945,7 +945,8 @@ int g_wgrad_big_rounds = 8;         // EESEG_OPT_WGRAD_BIG_ROUNDS: at most this 
 int g_wgrad_m16 = 0;                // eeseg_set_wgrad_big(on | 16): 256x256 kernel on v_mfma_f32_16x16x32_bf16
 int g_wgrad_slabs = 0;              // eeseg_set_wgrad_big(on | 4): 4 = combine the K splits through slabs (bitwise reproducible)
 int g_wgrad_coop = 1;               // eeseg_set_wgrad_big(on | 8): 8 (default) = combine the K splits INSIDE the kernel when its whole grid is resident
-int g_wgrad_group_max_ktiles = 640;  // eeseg_set_wgrad_group(n): weight gradients of at most this many 64-pixel K tiles are grouped (0 = never); 640 = 9 images of 65 x 65
+int g_wgrad_group_max_ktiles = 1 << 20;  // eeseg_set_wgrad_group(n): weight gradients of at most this many 64-pixel K tiles may be grouped (0 = never; default: no limit,
+                                         // the cost model in eeseg_conv_wgrad_group decides)
 int g_wgrad_target_blocks = 0;      // tiles * splits aimed at (eeseg_set_wgrad_target_blocks); 0 = by the cost model below
 
 // Cost model of the 128x128-tile kernel (fitted to scripts/wgrad_sweep.py, MI355X, us): a block takes ~1.0 us per
@@ -1202,16 +1203,45 @@ extern "C" int eeseg_conv_wgrad_group(const eeseg_wgrad_args* a, int n, void* st
     ok = ok && sum_tiles <= T && sum_tiles <= EESEG_BARRIER_GROUPS;
     WgGroup g;
     long long blocks = 0, slab_tiles = 0;
+    long long sp_of[WG_GROUP_MAX];
+    if (ok) {
+        // splits: one each, then one more for the problem with the most K tiles per block while its tiles still fit on the chip and a block
+        // keeps at least 4 K tiles (all blocks run at once: the launch lasts as long as its longest K range)
+        long long used = sum_tiles;
+        for (int i = 0; i < n; ++i) sp_of[i] = 1;
+        for (;;) {
+            int w = -1;
+            long long worst = 0;
+            for (int i = 0; i < n; ++i) {
+                const long long per = (kt[i] + sp_of[i] - 1) / sp_of[i];
+                if (per > worst) { worst = per; w = i; }
+            }
+            if (w < 0 || used + tiles[w] > T || sp_of[w] >= (kt[w] + 3) / 4) break;
+            ++sp_of[w];
+            used += tiles[w];
+        }
+        // does one launch pay?  ~1.3 us per K tile of the longest range + one launch's fixed cost, against the single calls each on the
+        // whole chip (their K split: one round of blocks, at least 8 K tiles each) with a launch's fixed cost apiece.  Small shards: always
+        // (32 us per call whatever its size, scripts/wgrad_group_probe.py); the 16 + 36 + 16 tiles of a layer-4 block at 32 images: no -
+        // three splits each leave a fifth of the chip idle where the single calls fill it
+        double grouped = 0.0, one_by_one = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double per = (double)((kt[i] + sp_of[i] - 1) / sp_of[i]);
+            if (per > grouped) grouped = per;
+            long long s1 = T / tiles[i];
+            if (s1 > kt[i] / 8) s1 = kt[i] / 8;
+            if (s1 < 1) s1 = 1;
+            one_by_one += 1.3 * (double)((kt[i] + s1 - 1) / s1) + 25.0;
+        }
+        grouped = 1.3 * grouped + 30.0;
+        ok = grouped < one_by_one;
+    }
     if (ok) {
         g.n = n;
         for (int i = 0; i < n; ++i) {
             const eeseg_wgrad_args& q = a[i];
             const long long M = (long long)q.N * q.Hout * q.Wout;
-            // blocks in proportion to the MFMA work, whole splits of the problem's tiles
-            long long sp = (long long)((double)T * ((double)tiles[i] * (double)kt[i] / work)) / tiles[i];
-            const long long max_sp = (kt[i] + 3) / 4;                       // at least 4 K tiles per block
-            if (sp > max_sp) sp = max_sp;
-            if (sp < 1) sp = 1;
+            long long sp = sp_of[i];
             long long chunk = (M + sp - 1) / sp;
             chunk = (chunk + 63) / 64 * 64;
             sp = (M + chunk - 1) / chunk;

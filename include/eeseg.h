@@ -157,9 +157,10 @@ int eeseg_conv_wgrad(const eeseg_wgrad_args* a, void* stream);
  * a few images one weight gradient has too little K to fill the chip - every call costs ~32 us whatever its block count; side by side
  * each problem gets a share of the CUs in proportion to its work, ~4x the K per block, a quarter of the combine traffic.  Taken when
  * EVERY problem qualifies for the 256x256 kernel's in-kernel combine (bf16, Cin and Cout multiples of 256, the same `workspace` and
- * `barrier_state` in all of them, output width on the same side of 64) and has at most eeseg_set_wgrad_group() K tiles of 64 pixels
- * (default 640 = 9 images of 65 x 65; 0 = never): otherwise - and that is not an error - the calls are issued one by one exactly as
- * eeseg_conv_wgrad would.  eeseg_last_kernel(3) = problems the last call put into one launch (0 = one by one).  Results are bitwise
+ * `barrier_state` in all of them, output width on the same side of 64), has at most eeseg_set_wgrad_group() K tiles of 64 pixels
+ * (default: no limit; 0 = never) and the launch's longest K range beats the single calls by the library's cost model (small shards:
+ * always; the 68 output tiles of a layer-4 block at 32 images: no): otherwise - and that is not an error - the calls are issued one by
+ * one exactly as eeseg_conv_wgrad would.  eeseg_last_kernel(3) = problems the last call put into one launch (0 = one by one).  Results are bitwise
  * reproducible; they differ from the single calls' in the last bits (another K split). */
 int eeseg_conv_wgrad_group(const eeseg_wgrad_args* a, int n, void* stream);
 int eeseg_set_wgrad_group(int max_ktiles);

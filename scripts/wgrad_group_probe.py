@@ -8,6 +8,8 @@ from ee_semantic_segmentation_amd import kernels as K
 from ee_semantic_segmentation_amd._lib import lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if len(sys.argv) > 2:
+    lib().eeseg_set_wgrad_group(int(sys.argv[2]))
 
 
 def timed(fn, n=10):

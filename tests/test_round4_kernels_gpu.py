@@ -457,12 +457,26 @@ def test_weight_gradient_group_falls_back_to_single_calls():
     """Problems that cannot share a launch (a batch too large for the grouping to pay, a layer the 256x256 kernel does not take) are
     issued one by one - bitwise what eeseg_conv_wgrad gives - and eeseg_last_kernel(3) says so."""
     from ee_semantic_segmentation_amd._lib import lib
-    items = _wgrad_items(12, 65, 65)                    # 793 K tiles of 64 pixels: above the default limit of 640
+    items = _wgrad_items(4, 65, 65)                     # 265 K tiles of 64 pixels
     single = [K.conv_wgrad(x, dy, r, s, st, p, d) for x, dy, r, s, st, p, d in items]
     outs = [torch.empty_like(o) for o in single]
-    K.conv_wgrad_group([it + (o, False) for it, o in zip(items, outs)])
+    assert lib().eeseg_set_wgrad_group(200) == 0        # ... above the limit set here
+    try:
+        K.conv_wgrad_group([it + (o, False) for it, o in zip(items, outs)])
+    finally:
+        lib().eeseg_set_wgrad_group(1 << 20)
     assert lib().eeseg_last_kernel(3) == 0
     assert all(torch.equal(a, b) for a, b in zip(outs, single))
+    # the cost model: the 16 + 36 + 16 output tiles of a layer-4 block at 16 images leave the chip part idle when grouped
+    g4 = torch.Generator().manual_seed(9)
+    big = []
+    for cin, cout, k, d in ((2048, 512, 1, 1), (512, 512, 3, 4), (512, 2048, 1, 1)):
+        big.append((torch.randn(16, 65, 65, cin, generator=g4).to(DEV).bfloat16(), torch.randn(16, 65, 65, cout, generator=g4).to(DEV).bfloat16(),
+                    k, k, 1, d * (k // 2), d))
+    bouts = [torch.empty(it[1].shape[-1], it[2], it[3], it[0].shape[-1], device=DEV) for it in big]
+    K.conv_wgrad_group([it + (o, False) for it, o in zip(big, bouts)])
+    assert lib().eeseg_last_kernel(3) == 0
+    del big, bouts
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 33, 33, 64, generator=g).to(DEV).bfloat16()
     dy = torch.randn(2, 33, 33, 64, generator=g).to(DEV).bfloat16()
