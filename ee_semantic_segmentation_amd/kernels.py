@@ -88,6 +88,17 @@ def _prof_end(ev, family, flops, nbytes=0.0, tag=""):
     PROFILE.append((family, flops, ev, end, nbytes, tag))
 
 
+class _EventShare:
+    """A start event that attributes only `share` of the elapsed time to its record: the members of ONE launch (a weight-gradient
+    group) each get their part of the launch's time, in proportion to their FLOPs."""
+
+    def __init__(self, ev, share):
+        self.ev, self.share = ev, share
+
+    def elapsed_time(self, end):
+        return self.ev.elapsed_time(end) * self.share
+
+
 _ws_retired = []     # superseded scratch buffers: a captured HIP graph may still hold their addresses
 
 
@@ -375,16 +386,20 @@ def conv_wgrad_group(items):
     shards), else one by one.  items: [(x, dy, R, S, stride, pad, dil, out, accumulate)] - `out` fp32 KRSC, written / added in place."""
     assert 1 <= len(items) <= 4
     arr = (WgradArgs * len(items))()
-    flops = byts = 0.0
+    fb = []
     for a, it in zip(arr, items):
         _need_cuda(it[0], it[1])
-        f, b = _wgrad_args(a, *it)
-        flops, byts = flops + f, byts + b
+        fb.append(_wgrad_args(a, *it))
     ev = _prof_begin()
     check(lib().eeseg_conv_wgrad_group(arr, len(items), _stream()), "eeseg_conv_wgrad_group")
     if ev is not None:
-        n = lib().eeseg_last_kernel(3)
-        _prof_end(ev, "conv_wgrad_group" if n else "conv_wgrad (group issued one by one)", flops, byts, f"wgrad group of {len(items)}")
+        # one launch (or a run of single calls): every member gets its share of the elapsed time, by FLOPs, under its own layer tag
+        fam = "conv_wgrad_group_kernel" if lib().eeseg_last_kernel(3) else "conv_wgrad (group issued one by one)"
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        total = sum(f for f, _ in fb)
+        for (f, b), it in zip(fb, items):
+            PROFILE.append((fam, f, _EventShare(ev, f / total), end, b, f"{it[2]}x{it[3]} wgrad {it[0].shape[-1]}->{it[1].shape[-1]} d{it[6]}"))
 
 
 def pack_weight(w, dtype, cout_pad=None, want_fwd=True, want_bwd=True):
