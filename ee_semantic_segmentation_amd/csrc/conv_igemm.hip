@@ -2574,22 +2574,31 @@ int g_conv_pws = 1;           // EESEG_OPT_CONV_PWS: Cin = 256 expanding pointwi
 int g_conv_big_cus = 256;        // EESEG_OPT_CONV_CUS: CUs a launch may count on (< 256 while RCCL kernels hold some)
 int g_last_conv_kernel = 0;    // eeseg_last_kernel(0): which kernel the last eeseg_conv_igemm call launched (EESEG_KERNEL_*)
 int g_last_stats_rows = 0;     // eeseg_last_kernel(2): rows of `stats` that call wrote (one per pixel tile of the kernel it chose)
-int g_conv_sm = 1;             // EESEG_OPT_CONV_SMALL_M: layers with <= CUs/2 tiles of 256 x 256 (per-GPU shards) run on the 64/96/128-pixel
+int g_conv_sm = 2;             // EESEG_OPT_CONV_SMALL_M (2 = 1 + the tile choice by rounds for pointwise layers of a few rounds): layers with <= CUs/2 tiles of 256 x 256 (per-GPU shards) run on the 64/96/128-pixel
                                // tile kernel (one round of whole tiles) instead of K-split tiles + fix-up on the 256-tile kernel
 int g_conv_sm_deep = 1;        // EESEG_OPT_CONV_SMALL_M_DEEP: launches of <= one block per CU use the six-stage ring
 int g_conv_sm_max_nk = 160;    // EESEG_OPT_CONV_SMALL_M_MAX_K: ... when the K loop has at most this many 32-channel tiles (taps x Cin / 32)
 
-// pixel tile of conv_pw_kernel for a small layer: the tile whose busiest CU has the least work (blocks per CU x (pixels + a
-// per-block fixed cost worth ~40 pixels)); at most two blocks per CU (72 KiB of LDS each)
-int pick_small_bm(long long M, int n_tiles, int cus) {
+// pixel tile of conv_pw_kernel for a small layer: the tile whose busiest CU has the least work (rounds of blocks x (pixels + a
+// per-block fixed cost worth ~40 pixels)).  A launch of <= one block per CU runs the six-stage ring alone on its CU; anything bigger
+// runs two blocks per CU (72 KiB of LDS each), each of them ~1.5x slower than alone.  wide (EESEG_OPT_CONV_SMALL_M = 2, default): the
+// same choice for pointwise layers of a few rounds that are NOT small by the 256-tile count - 4 x 65 x 65 x (256 -> 1024) is 532
+// blocks of 128 pixels on 512 slots, i.e. two rounds for 1.04 rounds of work; 708 blocks of 96 pixels are two rounds of a smaller tile
+int pick_small_bm(long long M, int n_tiles, int cus, bool wide = false) {
     int best = PW_BM;
-    long long best_cost = -1;
+    double best_cost = -1.0;
     const int cand[3] = {64, 96, 128};
     for (int k = 0; k < 3; ++k) {
         const int bm = cand[k];
         const long long blocks = ((M + bm - 1) / bm) * n_tiles;
-        if (blocks > 2ll * cus && bm != PW_BM) continue;
-        const long long cost = ((blocks + cus - 1) / cus) * (bm + 40);
+        double cost;
+        if (wide) {
+            const long long slots = blocks <= cus ? cus : 2ll * cus;
+            cost = (double)((blocks + slots - 1) / slots) * (bm + 40) * (blocks <= cus ? 1.0 : 1.5);
+        } else {
+            if (blocks > 2ll * cus && bm != PW_BM) continue;
+            cost = (double)(((blocks + cus - 1) / cus) * (bm + 40));
+        }
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
     }
     return best;
@@ -2799,7 +2808,7 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_pws = value;
         return EESEG_OK;
     }
-    if (key == EESEG_OPT_CONV_SMALL_M && (value == 0 || value == 1)) {
+    if (key == EESEG_OPT_CONV_SMALL_M && value >= 0 && value <= 2) {
         g_conv_sm = value;
         return EESEG_OK;
     }
@@ -2995,7 +3004,10 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
             // round 4: at small M the pixel tile is chosen so that one round of whole tiles covers the chip (4 x 65 x 65: 96 pixels)
-            return launch_pw(p, M, sm ? pick_small_bm(M, p.n_tiles, g_conv_big_cus) : PW_BM, false, st);
+            // (wide: layers of at most 6 rounds of 128-pixel blocks pick their tile by rounds too)
+            const bool few = g_conv_sm == 2 && ((M + PW_BM - 1) / PW_BM) * p.n_tiles <= 6ll * g_conv_big_cus;
+            return launch_pw(p, M, sm ? pick_small_bm(M, p.n_tiles, g_conv_big_cus, g_conv_sm == 2)
+                                      : few ? pick_small_bm(M, p.n_tiles, g_conv_big_cus, true) : PW_BM, false, st);
         }
         // round 4: the 3x3 / dilated layers of a shard on the same kernel with a tap loop - one launch of whole tiles where the
         // 256-tile kernel would run EVERY tile as K ranges + a fix-up launch (4 x 65 x 65, 3x3 256->256: 56 -> see DESIGN.md)
@@ -3004,7 +3016,7 @@ extern "C" int eeseg_conv_igemm(const eeseg_conv_args* a, void* stream) {
 #ifdef EESEG_PW_STAMPS
             p.slabs = reinterpret_cast<float*>(a->workspace);
 #endif
-            return launch_pw(p, M, pick_small_bm(M, p.n_tiles, g_conv_big_cus), true, st);
+            return launch_pw(p, M, pick_small_bm(M, p.n_tiles, g_conv_big_cus, g_conv_sm == 2), true, st);
         }
         p.n_tiles = a->Cout / BIGT;             // p.m_tiles stays the 128-pixel count (stats rows)
         g_last_conv_kernel = EESEG_KERNEL_CONV_BIG;

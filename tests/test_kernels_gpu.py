@@ -40,7 +40,7 @@ def _keep_256_tile_tests_on_the_256_tile_kernel(request):
     try:
         yield
     finally:
-        lib().eeseg_set_option(21, 1)
+        lib().eeseg_set_option(21, 2)
 
 
 def rnd(dtype, *shape, seed=0, scale=1.0):
@@ -1183,7 +1183,7 @@ def test_conv_256_tile_mfma_16x16x32(case):
         lib().eeseg_set_option(17, 1)
         lib().eeseg_set_option(19, SWP_DEFAULT)
         lib().eeseg_set_option(13, 1280)
-        lib().eeseg_set_option(21, 1)
+        lib().eeseg_set_option(21, 2)
     for m16, (y, sums) in outs.items():
         close(nchw(y), want, tol(torch.bfloat16), f"mfma16={m16} vs torch")
         if sums is not None:

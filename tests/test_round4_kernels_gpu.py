@@ -166,6 +166,7 @@ SMALL_M_CASES = [
     (2, 33, 31, 256, 256, 3, 1, 4, 4, 64),       # dilation 4, 32 tiles of 64 px, taps partly outside
     (1, 20, 23, 128, 512, 3, 1, 1, 1, 64),       # two cout tiles, Cin = 128 (4 K tiles per tap)
     (2, 65, 65, 64, 256, 3, 2, 1, 1, 64),        # stride 2 forward (gather is linear in the tap): 33 x 33 outputs
+    (4, 65, 65, 256, 1024, 1, 1, 0, 1, 96),      # not small by the 256-tile count, but 532 blocks of 128 px = two rounds for 1.04: 96-px tiles
     (8, 65, 65, 256, 256, 3, 1, 2, 2, 0),        # 8 images: 133 tiles of 256 > CUs / 2 -> stays on the 256-tile kernel
 ]
 
@@ -213,7 +214,7 @@ def test_conv_small_m_kernel_vs_torch(case):
         yd0, part0 = K.conv_fwd(xd, wf, s, p, d, want_stats=True)
         assert not bm or lib().eeseg_last_kernel(0) != 4 or k == 1
     finally:
-        lib().eeseg_set_option(21, 1)
+        lib().eeseg_set_option(21, 2)
     close(yd, yd0, 8e-3, "small-M kernel vs round-3 dispatch")
     close(K.reduce_partials(part0), sums, 2e-3, "stats vs round-3 dispatch")
     if Cin % 256 == 0 and s == 1:
