@@ -1366,8 +1366,15 @@ constexpr int pw_lds(int nst) { return (PW_EPI > nst * PW_STAGE ? PW_EPI : nst *
 //         one block per CU: a lone block streams its K tiles at (bytes in flight) / (L2 latency) - two 22-KiB tiles in
 //         flight gave ~40 GB/s per block, i.e. 0.55 us per K tile against 0.18 us of MFMA work (3x3 256->256 at 4 images:
 //         46 us); five tiles in flight are what the second block's LDS buys when there is no second block.
-template <int BMT, bool TAPS, int NST>
-__global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) {
+//   KW:   wave groups of the deep form (NST > 3 only).  2 = eight waves: waves 4-7 mirror waves 0-3 (same couts, same pixels) and
+//         each group multiplies ONE of the two 16-channel k-steps of every K tile, so a SIMD holds two waves whose MFMAs, fragment
+//         reads and DMA issues interleave (one wave per SIMD is issue-bound: 765 cycles per K tile for 384 cycles of MFMAs); the two
+//         partial accumulator sets are added through LDS after the K loop and waves 4-7 leave before the epilogue.
+template <int BMT, bool TAPS, int NST, int KW = 1>
+__global__ __launch_bounds__(256 * KW, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) {
+    static_assert(KW == 1 || (KW == 2 && NST > 3), "two wave groups: deep form only");
+    constexpr int KS = 2 / KW;                               // k-steps of a K tile a wave multiplies
+    constexpr int NXQ = 2 / KW, NWQ = 4 / KW;                // LDS-DMA instructions per wave and K tile: activations, weights
     typedef bf16_t T;
     typedef Mma<T>::Frag Frag;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1375,7 +1382,9 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
     constexpr int J = BMT / 32;                              // 32-pixel MFMA column blocks per wave
     __shared__ __attribute__((aligned(16))) char smem[pw_lds(NST)];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;                              // cout quarter (and the wave index of everything behind the K loop)
+    const int kh = KW == 2 ? wave8 >> 2 : 0;                 // which k-step of a K tile this wave multiplies (KW == 2)
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % p.n_tiles, mt = bid / p.n_tiles;    // cout tiles fastest: the 1..8 blocks that share a pixel tile are neighbours
     const int m0 = mt * BMT, n0 = nt * PW_BN;
@@ -1396,13 +1405,14 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
         const int lrow = lane >> 2, slot = lane & 3;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.xbytes);
         const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, p.wbytes);
-        uint32_t voffX[2], voffW[4];
-        int baseX[2];                                        // TAPS: byte offset of the tap-(0,0) source pixel of the lane's rows (may be negative)
-        unsigned vmask[2] = {0u, 0u};                        // TAPS: taps that land inside the image, per row
+        uint32_t voffX[NXQ], voffW[NWQ];
+        int baseX[NXQ];                                      // TAPS: byte offset of the tap-(0,0) source pixel of the lane's rows (may be negative)
+        unsigned vmask[NXQ];                                 // TAPS: taps that land inside the image, per row
         const int taps = TAPS ? p.R * p.S : 1;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int r = (wave * 2 + q) * 16 + lrow;
+        for (int q = 0; q < NXQ; ++q) {
+            vmask[q] = 0u;
+            const int r = (wave8 * NXQ + q) * 16 + lrow;
             const int m = m0 + r;
             const bool on = r < BMT && m < p.M;
             if constexpr (TAPS) {
@@ -1427,8 +1437,8 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = (wave * 4 + q) * 16 + lrow;
+        for (int q = 0; q < NWQ; ++q) {
+            const int r = (wave8 * NWQ + q) * 16 + lrow;
             voffW[q] = (uint32_t)((n0 + r) * taps * p.Cin * 2 + ((slot ^ ((r >> 2) & 3)) << 4));
         }
         const int nkc = p.Cin / 32;                          // K tiles per tap
@@ -1439,7 +1449,7 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
             const int r = tap / p.S, s_ = tap - r * p.S;
             const int dtap = ((r * p.tstep_h) * p.Win + s_ * p.tstep_w) * p.Cin * 2;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) voffX[q] = ((vmask[q] >> tap) & 1u) ? (uint32_t)(baseX[q] + dtap) : EESEG_OOB;
+            for (int q = 0; q < NXQ; ++q) voffX[q] = ((vmask[q] >> tap) & 1u) ? (uint32_t)(baseX[q] + dtap) : EESEG_OOB;
         };
         if constexpr (TAPS) set_tap(0);
         auto issue = [&](int kt, int st) {
@@ -1448,12 +1458,12 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
             const int sW = kt * PW_ROW;                      // weights [cout][tap][cin]: K tile kt = tap * nkc + ci starts kt * 64 bytes into a row
             char* sx = smem + st * PW_STAGE;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16,
+            for (int q = 0; q < NXQ; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave8 * NXQ + q) * 1024), 16,
                                                          (int)(live ? voffX[q] : EESEG_OOB), soffX, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave * 4 + q) * 1024), 16,
+            for (int q = 0; q < NWQ; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave8 * NWQ + q) * 1024), 16,
                                                          (int)(live ? voffW[q] : EESEG_OOB), sW, 0, 0);
             if constexpr (TAPS) {                            // advance to K tile kt + 1
                 if (++it_ci == nkc) {
@@ -1469,23 +1479,23 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
 #pragma unroll
         for (int q = 0; q < NST; ++q) issue(q, q);            // K tiles 0 .. NST-1 (past the end: out-of-range loads)
         PW_STAMP(1);
-        auto rdfr = [&](int st, Frag (&a)[2][2], Frag (&b)[J][2]) {
+        auto rdfr = [&](int st, Frag (&a)[2][KS], Frag (&b)[J][KS]) {
             const char* sb = smem + st * PW_STAGE;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const char* r = sb + PW_XS + (wave * 64 + i * 32 + fr) * PW_ROW;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+                for (int ks = 0; ks < KS; ++ks) a[i][ks] = *reinterpret_cast<const Frag*>(r + ((((ks + kh) * 2 + fh) ^ fsw) << 4));
             }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const char* r = sb + (j * 32 + fr) * PW_ROW;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) b[j][ks] = *reinterpret_cast<const Frag*>(r + (((ks * 2 + fh) ^ fsw) << 4));
+                for (int ks = 0; ks < KS; ++ks) b[j][ks] = *reinterpret_cast<const Frag*>(r + ((((ks + kh) * 2 + fh) ^ fsw) << 4));
             }
         };
-        Frag fa0[2][2], fb0[J][2], fa1[2][2], fb1[J][2];
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (NST - 1)) : "memory");       // K tile 0 landed
+        Frag fa0[2][KS], fb0[J][KS], fa1[2][KS], fb1[J][KS];
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NXQ + NWQ) * (NST - 1)) : "memory");       // K tile 0 landed
         BIG_BARRIER();
         rdfr(0, fa0, fb0);
         int s_cur = 0;                                         // stage of K tile t
@@ -1498,16 +1508,16 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
         // them (a lone wave per SIMD issues in order: memory instructions ahead of the MFMA block are serial time, between
         // two MFMAs they ride in the matrix pipe's shadow - diagnostic build: DMA issue 10 us, reads 9 us, MFMAs 14 us of a
         // 30-us loop when issued one after the other)
-        auto step = [&](int t, const Frag (&ac)[2][2], const Frag (&bc)[J][2], Frag (&an)[2][2], Frag (&bn)[J][2], bool first) {
+        auto step = [&](int t, const Frag (&ac)[2][KS], const Frag (&bc)[J][KS], Frag (&an)[2][KS], Frag (&bn)[J][KS], bool first) {
             // K tile t+1 landed (tiles t+2 .. t+NST-1 stay in flight) and this wave holds the fragments of tile t
 #ifdef EESEG_PW_CYCLES    // diagnostic build: shader-clock stamps of K tiles 16..19, block 0, per wave, behind the per-block stamps
 #define PW_CYC(i) if (blockIdx.x == 0 && lane == 0 && p.slabs && t >= 16 && t < 20) \
-    reinterpret_cast<unsigned long long*>(p.slabs)[8192 + ((t - 16) * 4 + wave) * 8 + (i)] = __builtin_readcyclecounter()
+    reinterpret_cast<unsigned long long*>(p.slabs)[8192 + ((t - 16) * 8 + wave8) * 8 + (i)] = __builtin_readcyclecounter()
 #else
 #define PW_CYC(i)
 #endif
             PW_CYC(0);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (NST - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NXQ + NWQ) * (NST - 2)) : "memory");
             PW_CYC(1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             PW_CYC(2);
@@ -1519,7 +1529,7 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
             char* sx = smem + s_cur * PW_STAGE;
             const int s_n = s_cur == NST - 1 ? 0 : s_cur + 1;
             const char* sbn = smem + s_n * PW_STAGE;
-            constexpr int NM = 4 * J, NO = 10 + 2 * J;
+            constexpr int NM = 2 * KS * J, NA = 2 * KS, NB = J * KS, NO = NA + NB + NXQ + NWQ;
 #pragma unroll
             for (int n = 0; n < NM; ++n) {
                 const int ks = n / (2 * J), j = (n / 2) % J, i = n & 1;
@@ -1536,23 +1546,23 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
                     if (k * NM / NO != n) continue;            // memory op k rides behind MFMA number k * NM / NO
                     // the fragment reads first: they must have landed at the top of the next step (an LDS read issued behind
                     // the last MFMA would be exposed latency), the DMA issues last (nobody waits for them for NST-1 steps)
-                    if (k < 4) {
-                        const int fi = k >> 1, fk = k & 1;
+                    if (k < NA) {
+                        const int fi = k / KS, fk = k % KS;
                         if (!(diag & 4))
-                            an[fi][fk] = *reinterpret_cast<const Frag*>(sbn + PW_XS + (wave * 64 + fi * 32 + fr) * PW_ROW + (((fk * 2 + fh) ^ fsw) << 4));
-                    } else if (k < 4 + 2 * J) {
-                        const int fj = (k - 4) >> 1, fk = (k - 4) & 1;
+                            an[fi][fk] = *reinterpret_cast<const Frag*>(sbn + PW_XS + (wave * 64 + fi * 32 + fr) * PW_ROW + ((((fk + kh) * 2 + fh) ^ fsw) << 4));
+                    } else if (k < NA + NB) {
+                        const int fj = (k - NA) / KS, fk = (k - NA) % KS;
                         if (!(diag & 4))
-                            bn[fj][fk] = *reinterpret_cast<const Frag*>(sbn + (fj * 32 + fr) * PW_ROW + (((fk * 2 + fh) ^ fsw) << 4));
-                    } else if (k < 6 + 2 * J) {
-                        const int q = k - 4 - 2 * J;
+                            bn[fj][fk] = *reinterpret_cast<const Frag*>(sbn + (fj * 32 + fr) * PW_ROW + ((((fk + kh) * 2 + fh) ^ fsw) << 4));
+                    } else if (k < NA + NB + NXQ) {
+                        const int q = k - NA - NB;
                         if (!(diag & 2))
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave * 2 + q) * 1024), 16,
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sx + (wave8 * NXQ + q) * 1024), 16,
                                                                      (int)(live ? voffX[q] : EESEG_OOB), soffX, 0, 0);
                     } else {
-                        const int q = k - 6 - 2 * J;
+                        const int q = k - NA - NB - NXQ;
                         if (!(diag & 2))
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave * 4 + q) * 1024), 16,
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sx + PW_XS + (wave8 * NWQ + q) * 1024), 16,
                                                                      (int)(live ? voffW[q] : EESEG_OOB), sW, 0, 0);
                     }
                 }
@@ -1621,6 +1631,33 @@ __global__ __launch_bounds__(256, NST > 3 ? 1 : 2) void conv_pw_kernel(ConvP p) 
         PW_STAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // trailing out-of-range DMAs still write (zeros) into LDS
         __syncthreads();
+        if constexpr (KW == 2) {
+            // the two k-halves of every accumulator meet in LDS (the ring is idle now): waves 4-7 write theirs (24 x 16 bytes per lane,
+            // [quarter][register group][lane]) and leave - the hardware barrier counts the waves that are still there -, waves 0-3 add
+            f32x4* xb = reinterpret_cast<f32x4*>(smem) + (size_t)wave * (2 * J * 4) * 64 + lane;
+            if (kh == 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            xb[((i * J + j) * 4 + g) * 64] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            }
+            __syncthreads();
+            if (kh == 1) return;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = xb[((i * J + j) * 4 + g) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += o[e];
+                    }
+            __syncthreads();                                   // (four waves from here on) the exchange area becomes the staging area
+        }
     }
     PW_STAMP(3);
 
@@ -2610,7 +2647,9 @@ int launch_pw(ConvP& p, long long M, int bm, bool taps, hipStream_t st) {
     // at most one block per CU: the deep ring (six stages, 144 KiB) instead of room for a second block
     const bool deep = g_conv_sm_deep && (long long)p.m_tiles * p.n_tiles <= g_conv_big_cus;
 #define EESEG_LAUNCH_PW(BM_) { \
-        if (taps && deep) hipLaunchKernelGGL((conv_pw_kernel<BM_, true, 6>), grid, dim3(256), 0, st, p); \
+        if (taps && deep && g_conv_sm_deep == 2 && BM_ <= 96) hipLaunchKernelGGL((conv_pw_kernel<BM_ <= 96 ? BM_ : 96, true, 6, 2>), grid, dim3(512), 0, st, p); \
+        else if (deep && g_conv_sm_deep == 2 && BM_ <= 96) hipLaunchKernelGGL((conv_pw_kernel<BM_ <= 96 ? BM_ : 96, false, 6, 2>), grid, dim3(512), 0, st, p); \
+        else if (taps && deep) hipLaunchKernelGGL((conv_pw_kernel<BM_, true, 6>), grid, dim3(256), 0, st, p); \
         else if (taps) hipLaunchKernelGGL((conv_pw_kernel<BM_, true, 3>), grid, dim3(256), 0, st, p); \
         else if (deep) hipLaunchKernelGGL((conv_pw_kernel<BM_, false, 6>), grid, dim3(256), 0, st, p); \
         else hipLaunchKernelGGL((conv_pw_kernel<BM_, false, 3>), grid, dim3(256), 0, st, p); }
@@ -2812,7 +2851,7 @@ extern "C" int eeseg_set_option(int key, int value) {
         g_conv_sm = value;
         return EESEG_OK;
     }
-    if (key == EESEG_OPT_CONV_SMALL_M_DEEP && (value == 0 || value == 1)) {
+    if (key == EESEG_OPT_CONV_SMALL_M_DEEP && value >= 0 && value <= 2) {
         g_conv_sm_deep = value;
         return EESEG_OK;
     }

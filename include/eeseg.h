@@ -40,7 +40,7 @@ int eeseg_version(void);
  * registers / ds_write; 1 K-step in flight); 1 or 2 = K-steps through staging registers; 3 = bf16 stride-1-gather convs
  * with Cout % 256 == 0 use the 256x256-tile kernel (8 waves, LDS-DMA loads in flight across raw barriers, counted vmcnt),
  * everything else as 0 (default). */
-enum { EESEG_OPT_CONV_SMALL_M_DEEP = 23 /* 1 (default): a launch of the 128x256 kernel with at most one block per CU uses six LDS-DMA stages (144 KiB, five K tiles in flight) instead of three: a lone block streams at bytes-in-flight / L2 latency */,
+enum { EESEG_OPT_CONV_SMALL_M_DEEP = 23 /* 1 (default): a launch of the 128x256 kernel with at most one block per CU uses six LDS-DMA stages (144 KiB, five K tiles in flight) instead of three: a lone block streams at bytes-in-flight / L2 latency; 2 = the same with EIGHT waves for tiles of <= 96 pixels (two wave groups, each multiplies one of the two k-steps of every K tile, partial sums added through LDS): measured neutral (33.9 vs 32.0 us on 3x3 256->256 at 4 images - the loop is bound by the 22 KiB every block pulls from L2 per K tile, not by instruction issue), kept as an A/B switch */,
        EESEG_OPT_CONV_SMALL_M_MAX_K = 22 /* ... when the K loop has at most this many 32-channel tiles, taps x Cin / 32 (default 160: everything of a ResNet shard but the 2048-wide atrous convs, whose long K loops stay on the 256-tile kernel) */,
        EESEG_OPT_CONV_SMALL_M = 21 /* 2 (default) = 1 + pointwise layers of at most 6 rounds of 128-pixel blocks pick their pixel tile by ROUNDS of blocks too (4 x 65 x 65 x 256 -> 1024: 708 blocks of 96 pixels instead of 532 of 128 on 512 slots); 1: bf16 layers with <= CUs / 2 tiles of 256 x 256 (the 4-8 image shards of a data-parallel run) run on the 128x256 kernel with a 64 / 96 / 128 pixel tile chosen so that ONE round of whole tiles covers the chip, 3x3 / dilated layers included (tap loop); 0 = round-3 dispatch (K-split tiles + fix-up launch on the 256-tile kernel) */,
        EESEG_OPT_BN_NT = 20 /* bit 0: bn_apply, bit 1: bn_bwd_apply load the tensors that are dead after the pass (conv output / residual; dy / conv output) with a nontemporal hint (default 0) */,

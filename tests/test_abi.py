@@ -87,7 +87,7 @@ def test_option_table_round_trips(built_lib):
              "EESEG_OPT_CONV_TAIL_MERGE": (1, 0, 2), "EESEG_OPT_CONV_CUS": (256, 240, 8), "EESEG_OPT_BN_REVERSE": (0, 3, 4),
              "EESEG_OPT_BN_ROWS": (2, 4, 3), "EESEG_OPT_COLREDUCE_BLOCKS": (512, 0, -1), "EESEG_OPT_CONV_SPLIT_MIN_K": (4, 8, 0),
              "EESEG_OPT_CONV_PW_MAX_K": (1280, 0, -1), "EESEG_OPT_CONV_PWS": (1, 2, 6), "EESEG_OPT_CONV_PW_ALL": (0, 1, 2), "EESEG_OPT_CONV_COUT_GROUP": (0, 2, 3), "EESEG_OPT_CONV_MFMA16": (1, 0, 2), "EESEG_OPT_BN_BWD_ROWS": (1, 2, 3), "EESEG_OPT_CONV_SWP": (1, 0, 2), "EESEG_OPT_BN_NT": (0, 3, 4),
-             "EESEG_OPT_CONV_SMALL_M": (2, 0, 3), "EESEG_OPT_CONV_SMALL_M_MAX_K": (160, 64, -1), "EESEG_OPT_CONV_SMALL_M_DEEP": (1, 0, 2)}
+             "EESEG_OPT_CONV_SMALL_M": (2, 0, 3), "EESEG_OPT_CONV_SMALL_M_MAX_K": (160, 64, -1), "EESEG_OPT_CONV_SMALL_M_DEEP": (1, 2, 3)}
     assert set(table) == set(keys), set(table) ^ set(keys)
     for name, (default, other, bad) in table.items():
         k = keys[name]

@@ -171,8 +171,18 @@ SMALL_M_CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 2], ids=["one_wave_group", "two_wave_groups"])
+def deep_form(request):
+    """EESEG_OPT_CONV_SMALL_M_DEEP: 1 = four waves, 2 = eight waves (two groups, each one k-step of every K tile, tiles <= 96 pixels)"""
+    from ee_semantic_segmentation_amd._lib import lib
+    prev = lib().eeseg_get_option(23)
+    assert lib().eeseg_set_option(23, request.param) == 0
+    yield request.param
+    lib().eeseg_set_option(23, prev)
+
+
 @pytest.mark.parametrize("case", SMALL_M_CASES, ids=[str(c) for c in SMALL_M_CASES])
-def test_conv_small_m_kernel_vs_torch(case):
+def test_conv_small_m_kernel_vs_torch(case, deep_form):
     """forward + BN partial sums, fused scale / shift / residual / ReLU, slice output, data-gradient (plain, accumulating,
     masked-residual) of the small-M kernel against F.conv2d / its autograd; the dispatch (kernel id, stats rows) as documented;
     switching the path off (EESEG_OPT_CONV_SMALL_M = 0) gives the round-3 kernels and the same numbers to bf16 rounding."""
