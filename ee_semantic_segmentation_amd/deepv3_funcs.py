@@ -78,7 +78,9 @@ def train_deepv3(net, num_epochs, kwargs):
         optimizer = SGD(params, lr=lr, momentum=.9, weight_decay=5e-4)
     else:
         optimizer = SGD(net.parameters(), lr=lr, momentum=.9, weight_decay=5e-4)
-    if not freeze_backbone and hasattr(net, "enable_grad_arena") and device.type == "cuda":
+    if hasattr(net, "enable_grad_arena") and device.type == "cuda":
+        # (also with a frozen backbone: autograd then never enters the frozen sections' backward, their arena slices stay zero and
+        # the data-parallel reducer sends them with the buckets it launches at the end of the step - parallel.ArenaReducer.finish)
         net.enable_grad_arena()
         net.fused_outputs = True
 

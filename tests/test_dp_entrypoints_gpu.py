@@ -37,14 +37,15 @@ def _dts_info(workdir, loss_name, transport=None):
     from ee_semantic_segmentation_amd.get_seg_datasets import LoadDataset
     from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
     train_set, val_set, test_set = LoadDataset(DIM, None, num_classes=C, sizes=(4, 5, 7)).get_dataset(None, "voc_seg")
-    loss = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=2) if loss_name == "ce" else \
+    loss = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=2) if loss_name.startswith("ce") else \
         BSL.LovaszSoftmax(classes="present", ignore=C, n_branches=1)
+    freeze = loss_name.endswith("_frozen_backbone")        # deepv3_funcs.py:76-81: only the exits train
     return {"device": torch.device("cuda", 0), "name": "dp", "main_dir": workdir, "res_dir": os.path.join(workdir, "res"),
             "input_dim": DIM, "train_set": train_set, "val_set": val_set, "test_set": test_set,
             "use_file": os.path.join(workdir, "msgs.txt"), "def_prefetch": lambda x: 2, "def_nworkers": lambda x: 0,
             "metrics": ["mIoU"], "minimize": False, "n_branches": 1, "count_branches": False, "lr": 0.01, "min_lr": 0.0,
             "base_lr": 0.01, "num_epochs": EPOCHS, "batch_sizes": BATCH, "loss": loss, "use_scheduler": True,
-            "nout_channels": C, "skip": 0, "fine_tune": "", "freeze_backbone": False, "freeze_from": None,
+            "nout_channels": C, "skip": 0, "fine_tune": "", "freeze_backbone": freeze, "freeze_from": None,
             "weighted_lr": False, "branch_params": None, "type": "resnet50", "dp_transport": transport,
             # both runs step eagerly: a captured step re-draws its dropout masks from the device step counter, an eager
             # one from the host call counter - same distribution, different masks; the hook transport cannot be captured
@@ -108,7 +109,7 @@ def _child(rank, port, loss_name, workdir, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("loss_name", ["ce", "lovasz"])
+@pytest.mark.parametrize("loss_name", ["ce", "lovasz", "ce_frozen_backbone"])
 def test_eval_deepv3_two_ranks_equal_one_process(loss_name):
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp(prefix="eeseg_dpmain_")
@@ -155,10 +156,16 @@ def test_eval_deepv3_two_ranks_equal_one_process(loss_name):
     print("best epochs", whole["best_epoch"], r0["best_epoch"], "trackers", whole["tracker"], r0["tracker"],
           "test mIoU", whole["mIoU"], r0["mIoU"])
     assert r0["best_epoch"] == r1["best_epoch"] and r0["tracker"] == r1["tracker"]      # same decisions on every rank
+    frozen = [k for k in KEYS if loss_name.endswith("_frozen_backbone") and k.startswith("base_model") and "running" not in k]
+    for k in frozen:                 # a frozen backbone (VERDICT r3 missing 4): its weights never move, on any rank, in either run
+        for e in range(1, EPOCHS + 1):
+            assert torch.equal(r0[f"w{e}"][k], w0[k]) and torch.equal(whole[f"w{e}"][k], w0[k]), (k, e)
     for k in KEYS:
         for e in range(1, EPOCHS + 1):
             assert torch.equal(r0[f"w{e}"][k], r1[f"w{e}"][k]), (k, e)                 # identical replicas
         assert torch.equal(r0["w"][k], r1["w"][k]), k
+        if k in frozen:
+            continue
         # step 1 starts from identical weights, dropout masks included (eeseg_dropout index_offset): the two runs differ
         # only in the order the shard sums reach the BatchNorm statistics / gradients - the ReLU-mask band of DESIGN.md
         # section 5, as in test_dp_world2_gpu.py
@@ -176,7 +183,7 @@ def test_eval_deepv3_two_ranks_equal_one_process(loss_name):
         for a, v in zip(r0["tracker"][key], vals):
             assert abs(a - v) < 5e-3, (key, r0["tracker"][key], vals)
     if r0["best_epoch"] == whole["best_epoch"]:       # chance-level mIoU can rank the two epochs differently; when it
-        for k in KEYS:                                # does not, the FINAL model files agree as well
+        for k in [k for k in KEYS if k not in frozen]:   # does not, the FINAL model files agree as well
             cos, l2 = agree(r0["w"], whole["w"], k)
             assert cos > 0.85 and l2 < 0.6, (k, cos, l2)
         for k, v in whole["mIoU"].items():
