@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # EESEG_LIB: another build of the SAME ABI (same-box A/B of two builds); default = the in-tree library.  lib() refuses a
 # library whose eeseg_version() differs from ABI_VERSION: the ctypes signatures below are written for exactly that ABI
 LIB_PATH = os.environ.get("EESEG_LIB") or os.path.join(_HERE, "libeeseg.so")
-ABI_VERSION = 105      # bumped with every signature / struct change of include/eeseg.h (csrc/api.hip returns the same number)
+ABI_VERSION = 106      # bumped with every signature / struct change of include/eeseg.h (csrc/api.hip returns the same number)
 
 F32, BF16 = 0, 1
 
@@ -107,6 +107,8 @@ SIGNATURES = {
     "eeseg_preprocess_label_u8": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "eeseg_class_sums_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "eeseg_class_sums_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
+    "eeseg_focal_map_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "eeseg_focal_map_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "eeseg_argmax_pair_hist": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "eeseg_entropy_gate_active": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _i64, _vp]),
     "eeseg_argmax_exit": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -364,9 +364,32 @@ class FocalTverskyLoss(TverskyLoss):
         return self._forward_imp(y_pred, i, targets) ** self.gamma
 
 
+class _FocalMap(torch.autograd.Function):
+    """The unreduced focal map of one exit from its low-res logits (eeseg_focal_map_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, lr, target, C, H, W, gamma, alpha, alpha_mode):
+        lr = lr.contiguous()
+        out, void = K.focal_map_fwd(lr.detach(), C, target, H, W, gamma, alpha, alpha_mode)
+        if int(void.item()) > 0:
+            raise RuntimeError("Class values must be smaller than num_classes.")      # as the reference's gather
+        ctx.save_for_backward(lr, target, alpha if alpha is not None else torch.empty(0, device=lr.device))
+        ctx.meta = (C, H, W, gamma, alpha_mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dmap):
+        lr, target, alpha = ctx.saved_tensors
+        C, H, W, gamma, alpha_mode = ctx.meta
+        dlr = torch.zeros_like(lr)
+        K.focal_map_bwd(lr, C, target, H, W, gamma, dmap.float().contiguous(), dlr, alpha if alpha_mode else None, alpha_mode)
+        return dlr, None, None, None, None, None, None, None
+
+
 class FocalLoss(BrSegLoss):
-    """:113-131.  The reference returns the per-pixel map [N,H,W] and reduces it afterwards; the fused kernel
-    reduces on the fly, so only reduction 'mean' / 'sum' are available (the map is never materialised).
+    """:113-131.  The reference returns the per-pixel map [N,H,W] and reduces it afterwards; for reduction 'mean' / 'sum' the
+    fused kernel reduces on the fly (the map is never materialised), any other reduction returns the stacked maps
+    [E,N,H,W] (with alpha: [E,N,N,H,W] when faithful_alpha, as the reference's broadcast gives) from eeseg_focal_map_fwd.
 
     ``alpha``: the reference multiplies the [B,H,W] loss map by ``alpha[targets]`` of shape [B,1,H,W], which broadcasts
     to [B,B,H,W] - every image's loss is weighted by every image's alpha map (:126-129).  ``faithful_alpha=True``
@@ -378,8 +401,6 @@ class FocalLoss(BrSegLoss):
     def __init__(self, alpha=None, gamma=2, smooth=1e-6, reduction="mean", n_branches=1, weights=None,
                  faithful_alpha=True):
         super().__init__(smooth, reduction, n_branches, weights)
-        if reduction not in ("mean", "sum"):
-            raise NotImplementedError("fused FocalLoss reduces on the fly: reduction must be 'mean' or 'sum'")
         self.alpha = None if alpha is None else torch.as_tensor(alpha, dtype=torch.float32)
         self.gamma = gamma
         self.faithful_alpha = faithful_alpha
@@ -387,6 +408,10 @@ class FocalLoss(BrSegLoss):
     def _compute_loss(self, y_pred, i, targets):
         lr = _exit_lowres(y_pred, i)[0]
         alpha = None if self.alpha is None else self.alpha.to(lr.device).contiguous()
+        if self.reduction not in ("mean", "sum"):               # the unreduced map (:132 `return loss`)
+            lr, C, (H, W) = _exit_lowres(y_pred, i)
+            mode = 0 if alpha is None else (2 if self.faithful_alpha else 1)
+            return _FocalMap.apply(lr, targets, C, H, W, float(self.gamma), alpha, mode)
         batch_sum = alpha is not None and self.faithful_alpha and lr.shape[0] > 1
         _, _, _, F, _, hw = self._sums(y_pred, i, targets, gamma=float(self.gamma), alpha=alpha, alpha_batch_sum=batch_sum)
         # [N] per-image sums; 'mean' over [N,H,W] = sum / (N*H*W): scale so that BrSegLoss.forward's mean over dim 1 fits

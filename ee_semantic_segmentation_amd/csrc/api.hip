@@ -12,4 +12,4 @@ void eeseg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* eeseg_last_error(void) { return g_err; }
-extern "C" int eeseg_version(void) { return 105; }   // = _lib.ABI_VERSION; bump with every signature / struct change
+extern "C" int eeseg_version(void) { return 106; }   // = _lib.ABI_VERSION; bump with every signature / struct change

@@ -615,6 +615,153 @@ __global__ __launch_bounds__(256) void class_sums_bwd_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------- focal loss as a per-pixel MAP (reduction = 'none') ----
+// FocalLoss._compute_loss (branchy_seg_losses.py:113-131) returns the [N,H,W] map  -(1 - p_t)^gamma log p_t  and BrSegLoss.forward
+// (:24-38) hands it back unreduced for any reduction other than 'mean' / 'sum'.  Same span scheme and arithmetic as the focal term of
+// class_sums_fwd_kernel, written out instead of summed.  alpha (:126-129): mode 1 = the pixel's own alpha[t]; mode 2 = the reference's
+// broadcast of the [N,H,W] map against alpha[targets] of shape [N,1,H,W]: out[i][j][y][x] = loss[j][y][x] * alpha[t[i][y][x]],
+// an [N,N,H,W] tensor.  Pixels labelled outside [0,C) are counted in *void_count (the reference's gather fails on them) and get 0.
+__global__ __launch_bounds__(256) void focal_map_fwd_kernel(const float* __restrict__ lr, int ldc, const int64_t* __restrict__ target,
+                                                            int C, int h, int w, int H, int W, float gamma,
+                                                            const float* __restrict__ alpha, int alpha_mode, float* __restrict__ out,
+                                                            int* void_count) {
+    const int n = blockIdx.y, N = gridDim.y;
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int total = H * w;
+    const bool active = lane32 < C;
+    int voids = 0;
+    for (int it = blockIdx.x * 8 + half; it < total; it += gridDim.x * 8) {
+        const int x0 = it % w, y = it / w;
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        const int x1 = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + x1) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + x1) * ldc];
+        }
+        const int64_t* trow = target + ((long long)n * H + y) * W;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;
+            const long long tg = trow[x];
+            const bool labelled = tg >= 0 && tg < C;
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float ssum = half_sum(e);
+            float loss = 0.f;
+            if (labelled) {
+                const float zt = __shfl(z, (int)tg, 32);
+                const float logq = zt - (m + __logf(ssum));
+                const float q = __expf(logq);
+                loss = -__powf(fmaxf(1.f - q, 0.f), gamma) * logq;
+            } else if (lane32 == 0) {
+                ++voids;
+            }
+            if (alpha_mode == 2) {                            // [N(i)][N(n)][H][W]: lane i writes row i
+                for (int i = lane32; i < N; i += 32) {
+                    const long long ti = target[((long long)i * H + y) * W + x];
+                    out[(((size_t)i * N + n) * H + y) * W + x] = (ti >= 0 && ti < C) ? loss * alpha[(int)ti] : 0.f;
+                }
+            } else if (lane32 == 0) {
+                out[((size_t)n * H + y) * W + x] = (alpha_mode == 1 && labelled) ? loss * alpha[(int)tg] : loss;
+            }
+        }
+    }
+    if (voids) atomicAdd(void_count, voids);
+}
+
+// dlr += d(sum dmap * map) / d(lr): per pixel gf = dmap[n][y][x] (* alpha[t]) or, mode 2, sum_i dmap[i][n][y][x] * alpha[t[i][y][x]];
+// then the focal term of class_sums_bwd_kernel with that factor.
+__global__ __launch_bounds__(256) void focal_map_bwd_kernel(const float* __restrict__ lr, int ldc, const int64_t* __restrict__ target,
+                                                            int C, int h, int w, int H, int W, float gamma,
+                                                            const float* __restrict__ alpha, int alpha_mode,
+                                                            const float* __restrict__ dmap, float* dlr) {
+    const int n = blockIdx.y, N = gridDim.y;
+    const int lane32 = threadIdx.x & 31;
+    const int half = threadIdx.x >> 5;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const bool active = lane32 < C;
+    const int total = H * w;
+    for (int it = blockIdx.x * 8 + half; it < total; it += gridDim.x * 8) {
+        const int x0 = it % w, y = it / w;
+        int xa = (int)floorf(((float)x0 + 0.5f) / sw - 0.5f) - 1;
+        int xb = (int)ceilf(((float)x0 + 1.5f) / sw - 0.5f) + 1;
+        xa = (x0 == 0) ? 0 : max(xa, 0);
+        xb = min(xb, W - 1);
+        const Src sy = src_index(y, sh, h);
+        const int xn = min(x0 + 1, w - 1);
+        const float* base = lr + (size_t)n * h * w * ldc + lane32;
+        float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+        if (active) {
+            v00 = base[((size_t)sy.i0 * w + x0) * ldc];
+            v01 = base[((size_t)sy.i0 * w + xn) * ldc];
+            v10 = base[((size_t)sy.i1 * w + x0) * ldc];
+            v11 = base[((size_t)sy.i1 * w + xn) * ldc];
+        }
+        float a0 = 0.f, a1 = 0.f;
+        for (int x = xa; x <= xb; ++x) {
+            const Src sx = src_index(x, sw, w);
+            if (sx.i0 != x0) continue;
+            const long long tg = target[((long long)n * H + y) * W + x];
+            if (!(tg >= 0 && tg < C)) continue;                // (uniform over the half wave)
+            float gf;
+            if (alpha_mode == 2) {
+                gf = 0.f;
+                for (int i = 0; i < N; ++i) {
+                    const long long ti = target[((long long)i * H + y) * W + x];
+                    if (ti >= 0 && ti < C) gf += dmap[(((size_t)i * N + n) * H + y) * W + x] * alpha[(int)ti];
+                }
+            } else {
+                gf = dmap[((size_t)n * H + y) * W + x] * (alpha_mode == 1 ? alpha[(int)tg] : 1.f);
+            }
+            const float z = active ? sy.l0 * (sx.l0 * v00 + sx.l1 * v01) + sy.l1 * (sx.l0 * v10 + sx.l1 * v11)
+                                   : -INFINITY;
+            const float m = half_max(z);
+            const float e = active ? __expf(z - m) : 0.f;
+            const float s = half_sum(e);
+            const float pr = e / s;
+            const bool mine = lane32 == (int)tg;
+            const float zt = __shfl(z, (int)tg, 32);
+            const float logq = zt - (m + __logf(s));
+            const float q = __expf(logq);
+            const float omq = fmaxf(1.f - q, 0.f);
+            const float k = gamma == 0.f ? -1.f : gamma * __powf(omq, gamma - 1.f) * q * logq - __powf(omq, gamma);
+            const float r = gf * k * ((mine ? 1.f : 0.f) - pr);
+            if (sx.i1 == sx.i0) {
+                a0 += r;
+            } else {
+                a0 += sx.l0 * r;
+                a1 += sx.l1 * r;
+            }
+        }
+        if (!active) continue;
+        const int x1 = min(x0 + 1, w - 1);
+        float* r0 = dlr + (((size_t)n * h + sy.i0) * w) * ldc + lane32;
+        float* r1 = dlr + (((size_t)n * h + sy.i1) * w) * ldc + lane32;
+        const float wy0 = (sy.i1 == sy.i0) ? 1.f : sy.l0;
+        const float wy1 = (sy.i1 == sy.i0) ? 0.f : sy.l1;
+        if (a0 != 0.f) {
+            atomicAdd(r0 + (size_t)x0 * ldc, wy0 * a0);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x0 * ldc, wy1 * a0);
+        }
+        if (a1 != 0.f) {
+            atomicAdd(r0 + (size_t)x1 * ldc, wy0 * a1);
+            if (wy1 != 0.f) atomicAdd(r1 + (size_t)x1 * ldc, wy1 * a1);
+        }
+    }
+}
+
 // ------------------------------------------------- argmax + TP/FP/FN counts ----
 __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ lr, int ldc,
                                                                const int64_t* __restrict__ target, int N, int C, int h,
@@ -912,6 +1059,34 @@ extern "C" int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(class_sums_bwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc,
                        target, C, h, w, H, W, gS, gI, gF, gamma, alpha, alpha_batch_sum, dlogits_lr);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_focal_map_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                                  float gamma, const float* alpha, int alpha_mode, float* out, int32_t* void_count, void* stream) {
+    CHECK_LR("focal_map_fwd");
+    EESEG_CHECK(target && out && void_count, EESEG_ERR_ARG, "focal_map_fwd: null pointer");
+    EESEG_CHECK(gamma >= 0.f && alpha_mode >= 0 && alpha_mode <= 2 && (alpha_mode == 0 || alpha), EESEG_ERR_ARG,
+                "focal_map_fwd: gamma >= 0, alpha_mode 0 (none) / 1 (own label) / 2 (reference broadcast, needs alpha)");
+    long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(focal_map_fwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc, target,
+                       C, h, w, H, W, gamma, alpha, alpha_mode, out, (int*)void_count);
+    EESEG_LAUNCH_CHECK();
+    return EESEG_OK;
+}
+
+extern "C" int eeseg_focal_map_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                                  float gamma, const float* alpha, int alpha_mode, const float* dmap, float* dlogits_lr, void* stream) {
+    CHECK_LR("focal_map_bwd");
+    EESEG_CHECK(target && dmap && dlogits_lr, EESEG_ERR_ARG, "focal_map_bwd: null pointer");
+    EESEG_CHECK(gamma >= 0.f && alpha_mode >= 0 && alpha_mode <= 2 && (alpha_mode == 0 || alpha), EESEG_ERR_ARG,
+                "focal_map_bwd: gamma >= 0, alpha_mode 0 / 1 / 2 (1, 2 need alpha)");
+    long long blocks = ((long long)H * w + 8 * 8 - 1) / (8 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(focal_map_bwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, logits_lr, ldc, target,
+                       C, h, w, H, W, gamma, alpha, alpha_mode, dmap, dlogits_lr);
     EESEG_LAUNCH_CHECK();
     return EESEG_OK;
 }

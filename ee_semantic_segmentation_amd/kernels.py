@@ -844,6 +844,26 @@ def class_sums_bwd(lr, C_, target, H, W, gS, gI, gF, dlr, gamma=-1.0, alpha=None
     return dlr
 
 
+def focal_map_fwd(lr, C_, target, H, W, gamma, alpha=None, alpha_mode=0):
+    """-> (map [N,H,W] fp32, or [N,N,H,W] for alpha_mode 2; void_count int32[1])."""
+    N, h, w, ldc = _lr_dims(lr)
+    assert target.is_contiguous() and target.dtype == torch.int64 and target.numel() == N * H * W
+    out = torch.empty((N, N, H, W) if alpha_mode == 2 else (N, H, W), dtype=torch.float32, device=lr.device)
+    void = torch.zeros(1, dtype=torch.int32, device=lr.device)
+    check(lib().eeseg_focal_map_fwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, float(gamma), _p(alpha), int(alpha_mode), _p(out),
+                                    _p(void), _stream()), "eeseg_focal_map_fwd")
+    return out, void
+
+
+def focal_map_bwd(lr, C_, target, H, W, gamma, dmap, dlr, alpha=None, alpha_mode=0):
+    N, h, w, ldc = _lr_dims(lr)
+    assert dmap.is_contiguous() and dmap.dtype == torch.float32 and dmap.numel() == (N * N if alpha_mode == 2 else N) * H * W
+    assert dlr.shape == lr.shape and dlr.is_contiguous()
+    check(lib().eeseg_focal_map_bwd(_p(lr), ldc, _p(target), N, C_, h, w, H, W, float(gamma), _p(alpha), int(alpha_mode), _p(dmap),
+                                    _p(dlr), _stream()), "eeseg_focal_map_bwd")
+    return dlr
+
+
 def argmax_pair_hist(lr_a, lr_b, C_, H, W, hist=None):
     """Per-image contingency table [N,C,C] int32 of the upsampled argmax maps of two exits."""
     N, h, w, ldc = _lr_dims(lr_a)

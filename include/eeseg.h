@@ -354,6 +354,15 @@ int eeseg_class_sums_fwd(const float* logits_lr, int ldc, const int64_t* target,
 int eeseg_class_sums_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
                          const float* gS, const float* gI, const float* gF, float gamma, const float* alpha,
                          int alpha_batch_sum, float* dlogits_lr, void* stream);
+/* FocalLoss with reduction = 'none' (branchy_seg_losses.py:113-131 through BrSegLoss.forward :24-38): the per-pixel map
+ * -(1 - p_t)^gamma log p_t [N,H,W] fp32 of one exit from its low-res logits, and its backward (dlogits_lr += for an upstream
+ * gradient dmap of the map's shape).  alpha_mode 0: no alpha; 1: times alpha[t] of the pixel's own label; 2: the reference's
+ * broadcast against alpha[targets] of shape [N,1,H,W] - out / dmap are [N,N,H,W] with out[i][j] = map[j] * alpha[t[i]].
+ * *void_count (device int32, +=) counts pixels labelled outside [0,C) (the reference's gather fails on them; they get 0). */
+int eeseg_focal_map_fwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                        float gamma, const float* alpha, int alpha_mode, float* out, int32_t* void_count, void* stream);
+int eeseg_focal_map_bwd(const float* logits_lr, int ldc, const int64_t* target, int N, int C, int h, int w, int H, int W,
+                        float gamma, const float* alpha, int alpha_mode, const float* dmap, float* dlogits_lr, void* stream);
 /* Fused upsample + argmax of TWO exits -> per-image contingency table hist[N][C][C] int32 (+= per call):
  * hist[n][a][b] = pixels where exit A predicts a and exit B predicts b.  The similarity gates between consecutive
  * exits (MSE / NMI / variation of information of the label maps: sim_metrics.py:41-120, eval_br_sim.py:41-48,

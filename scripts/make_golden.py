@@ -46,10 +46,35 @@ def lovasz_variants():
     print("lovasz variants", {k: float(v) for k, v in out.items() if k[-1].isdigit() and not k.startswith(("y", "t", "cls", "void"))})
 
 
+def focal_unreduced():
+    """FocalLoss with reduction='none' (branchy_seg_losses.py:113-131 through BrSegLoss.forward :24-38): the stacked per-pixel maps
+    [E,B,H,W] - with alpha [E,B,B,H,W], the reference's broadcast of the map against alpha[targets] of shape [B,1,H,W] - and the
+    gradient of (map * seeded weights).sum() w.r.t. the scores.  Batch sizes 2, 1, 3."""
+    sys.path.insert(0, REF)
+    import branchy_seg_losses as RBSL
+    out = {}
+    for k, (seed, E, B, C, H, W, gamma) in enumerate([(50, 2, 2, 21, 9, 11, 2.0), (51, 3, 1, 5, 16, 12, 1.5), (52, 2, 3, 19, 8, 8, 0.0)]):
+        torch.manual_seed(seed)
+        y = torch.randn(E, B, C, H, W) * 2
+        t = torch.randint(0, C, [B, 1, H, W])
+        alpha = torch.linspace(0.5, 1.5, C)
+        out[f"y{k}"], out[f"t{k}"], out[f"gamma{k}"] = y.numpy(), t.numpy(), np.float64(gamma)
+        for name, a in (("plain", None), ("alpha", alpha)):
+            yy = y.clone().requires_grad_(True)
+            m = RBSL.FocalLoss(alpha=a, gamma=gamma, reduction="none", n_branches=E - 1)(yy, t)
+            wgt = torch.randn(m.shape, generator=torch.Generator().manual_seed(seed + 100))
+            (m * wgt).sum().backward()
+            out[f"{name}{k}"], out[f"{name}{k}_w"], out[f"{name}{k}_grad"] = m.detach().numpy(), wgt.numpy(), yy.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "focal_unreduced.npz"), **out)
+    print("focal unreduced", {k: v.shape for k, v in out.items() if k.startswith(("plain", "alpha")) and k[-1].isdigit()})
+
+
 def main():
     warnings.filterwarnings("ignore")
     if "--only-lovasz-variants" in sys.argv:       # add this fixture without rewriting the others
         return lovasz_variants()
+    if "--only-focal-unreduced" in sys.argv:
+        return focal_unreduced()
     sys.path.insert(0, REF)
     import my_pixelwise_xentropy as RX
     import branchy_seg_losses as RBSL

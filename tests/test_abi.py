@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_library_loads_and_reports_version(built_lib):
     from ee_semantic_segmentation_amd import _lib
     l = _lib.lib()
-    assert l.eeseg_version() == 105
+    assert l.eeseg_version() == 106
     assert l.eeseg_conv_stats_tiles(16, 65, 65) == (16 * 65 * 65 + 63) // 64      # allocation bound: one row per 64 pixels
     assert l.eeseg_colreduce_workspace(1, 64) > 0
 

@@ -918,6 +918,45 @@ def test_ssim_gate_matches_oracle():
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])
+def test_unreduced_focal_loss_matches_reference_vectors(k):
+    """FocalLoss(reduction='none') - VERDICT r3 missing 4 - on eeseg_focal_map_fwd / _bwd: the stacked per-pixel maps [E,B,H,W]
+    (with alpha and the default faithful_alpha: [E,B,B,H,W], the reference's broadcast) and the gradient of (map * weights).sum()
+    against vectors produced by the reference class (tests/golden/focal_unreduced.npz: batch sizes 2, 1, 3; gamma 2, 1.5, 0); the
+    intended per-pixel alpha form against the oracle; a void label fails like the reference's gather."""
+    import os
+    import numpy as np
+    from ee_semantic_segmentation_amd import branchy_seg_losses as B
+    from oracle import losses_ref as L
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "focal_unreduced.npz"))
+    y, t = torch.from_numpy(g[f"y{k}"]), torch.from_numpy(g[f"t{k}"])
+    E, C, gamma = y.shape[0], y.shape[2], float(g[f"gamma{k}"])
+    alpha = torch.linspace(0.5, 1.5, C)
+    for name, a in (("plain", None), ("alpha", alpha)):
+        yy = y.clone().to(DEV).requires_grad_(True)
+        m = B.FocalLoss(alpha=a, gamma=gamma, reduction="none", n_branches=E - 1)(yy, t.to(DEV))
+        want = g[f"{name}{k}"]
+        assert tuple(m.shape) == want.shape, (name, m.shape, want.shape)
+        assert np.abs(m.detach().cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max(), name
+        (m * torch.from_numpy(g[f"{name}{k}_w"]).to(DEV)).sum().backward()
+        wg = g[f"{name}{k}_grad"]
+        assert np.abs(yy.grad.cpu().numpy() - wg).max() <= 2e-4 * np.abs(wg).max() + 1e-8, name
+    yy = y.clone().to(DEV).requires_grad_(True)
+    m = B.FocalLoss(alpha=alpha, gamma=gamma, reduction="none", n_branches=E - 1, faithful_alpha=False)(yy, t.to(DEV))
+    yr = y.clone().requires_grad_(True)
+    mr = L.br_focal(yr, t, E, alpha=alpha, gamma=gamma, reduction="none", faithful_alpha=False)
+    assert tuple(m.shape) == tuple(mr.shape) == (E,) + tuple(t.squeeze(1).shape)
+    assert float((m.detach().cpu() - mr.detach()).abs().max()) <= 2e-5 * float(mr.abs().max())
+    wgt = torch.randn(mr.shape, generator=torch.Generator().manual_seed(7))
+    (m * wgt.to(DEV)).sum().backward()
+    (mr * wgt).sum().backward()
+    assert float((yy.grad.cpu() - yr.grad).abs().max()) <= 2e-4 * float(yr.grad.abs().max()) + 1e-8
+    tv = t.clone()
+    tv[0, 0, 0, 0] = C
+    with pytest.raises(RuntimeError):
+        B.FocalLoss(gamma=gamma, reduction="none", n_branches=E - 1)(y.to(DEV), tv.to(DEV))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
 def test_region_and_focal_losses_match_reference_vectors(k):
     """Dice / Jaccard / Tversky / FocalTversky / Focal on the fused class-sums kernels vs values and gradients produced
     by the reference classes (tests/golden/region_losses.npz), then from LOW-RES exits (upsample fused) vs the oracle."""

@@ -153,6 +153,25 @@ def test_region_and_focal_losses_oracle_matches_reference_vectors(golden_dir, k)
         assert np.abs(got - wg).max() <= 1e-5 * max(1e-6, np.abs(wg).max()) + 1e-9, name
 
 
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_unreduced_focal_oracle_matches_reference_vectors(golden_dir, k):
+    """FocalLoss(reduction='none') (branchy_seg_losses.py:113-131, :24-38): the stacked maps [E,B,H,W] - [E,B,B,H,W] with alpha,
+    the reference's broadcast - and the gradient of (map * weights).sum(), reference classes vs oracle/losses_ref.py."""
+    import torch
+    from oracle import losses_ref as L
+    g = np.load(os.path.join(golden_dir, "focal_unreduced.npz"))
+    y, t = torch.from_numpy(g[f"y{k}"]), torch.from_numpy(g[f"t{k}"])
+    E, C, gamma = y.shape[0], y.shape[2], float(g[f"gamma{k}"])
+    for name, alpha in (("plain", None), ("alpha", torch.linspace(0.5, 1.5, C))):
+        yy = y.clone().requires_grad_(True)
+        m = L.br_focal(yy, t, E, alpha=alpha, gamma=gamma, reduction="none")
+        want = g[f"{name}{k}"]
+        assert tuple(m.shape) == want.shape and np.abs(m.detach().numpy() - want).max() <= 1e-5 * np.abs(want).max(), name
+        (m * torch.from_numpy(g[f"{name}{k}_w"])).sum().backward()
+        wg = g[f"{name}{k}_grad"]
+        assert np.abs(yy.grad.numpy() - wg).max() <= 1e-5 * np.abs(wg).max() + 1e-9, name
+
+
 def test_ssim_oracle_against_direct_window_loops():
     """oracle.sim_ref.ssim (summed-area-table form) vs the definition written out with explicit 7x7 window loops
     (skimage.metrics.structural_similarity defaults; parity unpinned: scikit-image is absent)."""
