@@ -1201,7 +1201,7 @@ extern "C" int eeseg_conv_wgrad_group(const eeseg_wgrad_args* a, int n, void* st
         work += (double)tiles[i] * (double)kt[i];
     }
     ok = ok && sum_tiles <= T && sum_tiles <= EESEG_BARRIER_GROUPS;
-    WgGroup g;
+    WgGroup g{};
     long long blocks = 0, slab_tiles = 0;
     long long sp_of[WG_GROUP_MAX];
     if (ok) {

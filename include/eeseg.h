@@ -67,7 +67,8 @@ int eeseg_set_option(int key, int value);
 int eeseg_get_option(int key);   /* current value, or a negative error code */
 /* Which kernel the last eeseg_conv_igemm (which = 0) / eeseg_conv_wgrad (which = 1) call of this process launched - host-side
  * state for measurement code that attributes a timed call to a kernel (bench.py's per-kernel roofline); 0 = none yet.
- * which = 2: the number of `stats` rows the last eeseg_conv_igemm call wrote (depends on the pixel tile of the kernel chosen). */
+ * which = 2: the number of `stats` rows the last eeseg_conv_igemm call wrote (depends on the pixel tile of the kernel chosen);
+ * which = 3: the number of problems the last eeseg_conv_wgrad_group call put into ONE launch (0 = it issued them one by one). */
 enum { EESEG_KERNEL_CONV_IGEMM_128 = 1, EESEG_KERNEL_CONV_IGEMM_64 = 2, EESEG_KERNEL_CONV_BIG = 3 /* 256x256 tile (+ K-split tail, fix-up) */,
        EESEG_KERNEL_CONV_PW = 4 /* 128x256 pointwise */, EESEG_KERNEL_CONV_PWS = 5 /* weight-stationary pointwise */,
        EESEG_KERNEL_WGRAD_128 = 6, EESEG_KERNEL_WGRAD_BIG = 7 };
