@@ -7,6 +7,7 @@
 
 Tolerances as tests/test_kernels_gpu.py: fp32 2-3e-4 of the result scale (summation order), bf16 2-3e-2.
 """
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -497,3 +498,56 @@ def test_weight_gradient_group_falls_back_to_single_calls():
     K.conv_wgrad_group([it + (o, False) for it, o in zip(small, outs)])
     assert lib().eeseg_last_kernel(3) == 0
     assert all(torch.allclose(a, b, rtol=1e-5, atol=1e-4) for a, b in zip(outs, single))    # (the 64-channel layer sums with atomics)
+
+
+def test_engine_queues_a_units_weight_gradients_into_group_launches():
+    """engine.Config.queue_wgrad: with the gradient arena the weight gradients of a unit wait for `unit_done` and leave as
+    eeseg_conv_wgrad_group calls (bf16, ResNet-50 / 1 exit at 2 x 129 x 129: the 16-image-wide layer-3 / layer-4 blocks share launches);
+    the arena after backward equals the arena of the same backward with EESEG_GROUP_WGRAD off to fp32 summation order (another
+    K split), and every queue is empty when backward returns."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_model_gpu import _inputs, _pair
+    from ee_semantic_segmentation_amd._lib import lib
+    from ee_semantic_segmentation_amd import engine as E
+    from ee_semantic_segmentation_amd.my_pixelwise_xentropy import BrXEntropyLoss
+    C, B, img = 21, 2, 129
+    net, _ = _pair("deeplabv3_resnet50", 1, img)
+    net.cfg.compute_dtype = torch.bfloat16
+    net.train()
+    net.fused_outputs = True
+    net.enable_grad_arena()
+    X, y = _inputs(B, C, img, img)
+    crit = BrXEntropyLoss(ignore_index=C, b_reduction="sum", n_exits=2)
+    calls, grouped = [], []
+    orig = E.K.conv_wgrad_group
+
+    def spy(items):
+        orig(items)
+        calls.append(len(items))
+        grouped.append(lib().eeseg_last_kernel(3))
+
+    arenas = []
+    E.K.conv_wgrad_group = spy
+    try:
+        for on in (True, False):
+            net.cfg.group_wgrad = on
+            net.cfg.arena.flat.zero_()
+            torch.manual_seed(3)
+            loss = crit(net(X.to(DEV)), y.to(DEV))
+            loss.mean().backward()
+            net.cfg.run_deferred()
+            assert net.cfg._wgrad_queue == []
+            arenas.append(net.cfg.arena.flat.clone())
+            if on:
+                assert calls and max(calls) >= 3 and max(grouped) >= 3, (calls, grouped)
+                n_on = len(calls)
+            else:
+                assert len(calls) == n_on, "the switch still queued weight gradients"
+    finally:
+        E.K.conv_wgrad_group = orig
+    a, b = arenas
+    assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+    # same forward state is not guaranteed bit for bit between two forwards (DESIGN.md section 5: a last-bit BatchNorm statistic flips
+    # a ReLU mask here and there), so the bar is the one the model parity tests use for repeated bf16 backward passes
+    assert float((a - b).norm() / b.norm()) < 2e-2
