@@ -239,6 +239,15 @@ def kernel_events(run, nsteps):
     return prof
 
 
+def _coop_timeouts():
+    from ee_semantic_segmentation_amd import kernels as K
+    n = K.coop_timeouts()
+    if n:
+        sys.stderr.write(f"[bench] WARNING: {n} cooperative-kernel barrier state(s) report a launch whose grid was not co-resident: "
+                         "the gradients of this run are not to be trusted (lower EESEG_OPT_CONV_CUS / --reserve-cus)\n")
+    return n
+
+
 def roofline(prof, prof_steps, dtype, workload_key):
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     fam, k3, shapes = {}, [0.0, 0.0, 0], {}
@@ -417,6 +426,10 @@ def main():
                            # the per-rank step spread
                            "dp_lanes": (1 if getattr(run.net.cfg.comm, "single_lane", False) else 2) if run.net.cfg.comm is not None else None,
                            "defer_wgrad": bool(run.net.cfg.defer_wgrad),
+                           # the cooperative kernels (one-launch BatchNorm backward, weight-gradient combine / groups) need their whole
+                           # grid resident; a launch that found it was not gives up with WRONG results and sets a flag: must be 0
+                           "coop_timeouts": _coop_timeouts(),
+                           "group_wgrad": bool(getattr(run.net.cfg, "group_wgrad", False)),
                            "n_buckets": len(run.reducer.buckets) if run.reducer.active else 0,
                            "bucket_mib": [round((b - a) * 4 / 2 ** 20, 1) for _, _, a, b in run.reducer.buckets] if run.reducer.active else [],
                            "syncbn_collectives_per_step": getattr(run, "stat_collectives_per_step", None),

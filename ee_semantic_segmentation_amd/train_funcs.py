@@ -37,6 +37,12 @@ def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runn
         if hasattr(net, "cfg"):
             net.cfg.end_step()
         last = l.detach()
+    if hasattr(net, "cfg") and getattr(device, "type", str(device)) == "cuda":
+        # once per epoch (a host read): a cooperative kernel whose grid was not co-resident has given up with wrong results
+        from . import kernels as K
+        if K.coop_timeouts():
+            raise RuntimeError("a cooperative kernel (BatchNorm backward / weight-gradient combine) found its grid not co-resident: "
+                               "the gradients of this epoch are wrong - lower EESEG_OPT_CONV_CUS (parallel.ArenaReducer reserve_cus)")
     return last
 
 

@@ -176,3 +176,4 @@ def test_bench_two_ranks_plumbing_on_one_gpu():
     sp = cfg["step_ms_over_ranks"]
     assert 0 < sp["min"] <= sp["median"] <= sp["max"] and abs(sp["max"] - d["ms_per_step"]) < 1e-6 * sp["max"] + 1e-9
     assert cfg["defer_wgrad"] is False
+    assert cfg["coop_timeouts"] == 0 and cfg["group_wgrad"] is True
