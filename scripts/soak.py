@@ -2,7 +2,7 @@
 arena + HIP-graph replay, SGD momentum 0.9 / wd 5e-4 / lr 0.01) for N steps over a small fixed set of synthetic batches.
 Checks: every loss finite, the loss falls, every parameter gradient still lives in the arena at the end, no parameter
 went non-finite; an EAGER twin (no graph) started from the same weights follows the same losses for the first steps.
-usage: python scripts/soak.py [steps] [out.json]"""
+usage: python scripts/soak.py [steps] [out.json] [images per step = 32]"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,7 @@ import bench
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 out = sys.argv[2] if len(sys.argv) > 2 else None
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 dev = torch.device("cuda", 0)
 args = argparse.Namespace(overlap_wgrad=0, reserve_cus=None, no_graph=False, dp_transport="rccl")
 NB = 4                                                    # distinct batches, cycled
@@ -18,11 +19,11 @@ NB = 4                                                    # distinct batches, cy
 def make(no_graph):
     a = argparse.Namespace(**vars(args))
     a.no_graph = no_graph
-    return bench.Run("resnet101", 2, 19, 513, 32, "bf16", "ce", False, 1, 0, dev, a)
+    return bench.Run("resnet101", 2, 19, 513, BATCH, "bf16", "ce", False, 1, 0, dev, a)
 
 
 run = make(False)
-batches = [bench.synth_batch(32, 19, 513, 513, 100 + i, dev) for i in range(NB)]
+batches = [bench.synth_batch(BATCH, 19, 513, 513, 100 + i, dev) for i in range(NB)]
 losses = []
 t0 = time.time()
 for s in range(steps):
@@ -52,12 +53,13 @@ for s in range(12):
     lg.append(float(g2.runner(X, y).item()))
     le.append(float(e2.runner(X, y).item()))
 twin = max(abs(a - b) / abs(b) for a, b in zip(lg, le))
-res = {"workload": "R101 3 exits 19 classes 513x513 B=32 bf16, arena + HIP graph, 4 synthetic batches cycled",
+from ee_semantic_segmentation_amd import kernels as K  # noqa: E402
+res = {"workload": f"R101 3 exits 19 classes 513x513 B={BATCH} bf16, arena + HIP graph, 4 synthetic batches cycled", "coop_timeouts": K.coop_timeouts(),
        "steps": steps, "seconds": dt, "hip_graph": graph_used, "loss_first3_mean": first, "loss_last3_mean": last,
        "losses_every_10": losses, "all_losses_finite": all(v == v and abs(v) < 1e9 for _, v in losses),
        "grads_in_arena": in_arena, "params_finite": finite,
        "graph_vs_eager_first12_max_rel": twin, "graph_first12": lg, "eager_first12": le}
 print(json.dumps({k: v for k, v in res.items() if k not in ("losses_every_10", "graph_first12", "eager_first12")}))
-assert res["all_losses_finite"] and in_arena and finite and last < first and twin < 2e-2, "soak failed"
+assert res["all_losses_finite"] and in_arena and finite and last < first and twin < 2e-2 and res["coop_timeouts"] == 0, "soak failed"
 if out:
     json.dump(res, open(out, "w"), indent=1)

@@ -438,7 +438,7 @@ def _wgrad_items(B, H, W, seed=0):
     return items
 
 
-@pytest.mark.parametrize("shape", [(4, 65, 65), (3, 33, 47), (8, 65, 65)], ids=str)
+@pytest.mark.parametrize("shape", [(4, 65, 65), (3, 33, 47), (8, 65, 65), (32, 65, 65)], ids=str)
 def test_grouped_weight_gradients_match_the_single_calls(shape):
     """The three weight gradients of a bottleneck block (1x1 1024->256, 3x3 dilated 256->256, 1x1 256->1024) in ONE launch
     (eeseg_conv_wgrad_group) against three eeseg_conv_wgrad calls and against torch: same sums, another K split (fp32 rounding
