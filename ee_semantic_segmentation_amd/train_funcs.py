@@ -37,7 +37,7 @@ def train_epoch(net, train_iter, loss, updater, device=torch.device("cpu"), runn
         if hasattr(net, "cfg"):
             net.cfg.end_step()
         last = l.detach()
-    if hasattr(net, "cfg") and getattr(device, "type", str(device)) == "cuda":
+    if hasattr(net, "cfg") and str(getattr(device, "type", device)).startswith("cuda"):
         # once per epoch (a host read): a cooperative kernel whose grid was not co-resident has given up with wrong results
         from . import kernels as K
         if K.coop_timeouts():
