@@ -481,8 +481,8 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             # the per-GPU shards of the N-GPU strong-scaling runs (global B=32) on THIS one GPU, no collectives: what the
-            # kernels alone allow at N = 4 and N = 8 (the >= 6x target is decided by the small-M kernels first)
-            for bs in (8, 4):
+            # kernels alone allow at N = 2, 4 and 8 (the >= 6x target is decided by the small-M kernels first)
+            for bs in (16, 8, 4):
                 r4 = Run(headline[0], headline[1], headline[2], headline[3], bs, "bf16", "ce", False, 1, 0, dev, args)
                 d4, l4, _ = timed(r4, max(args.steps, 20), args.warmup, 1, 1, args.no_graph)
                 n4 = max(args.steps, 20)
