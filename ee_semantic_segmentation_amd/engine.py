@@ -57,6 +57,10 @@ class Config:
         # library can put them side by side (eeseg_conv_wgrad_group: per-GPU shards of a few images; bigger batches are issued one by
         # one, just later) - arena mode only (the kernel writes the gradient in place, nothing to hand back to autograd)
         self.group_wgrad = __import__("os").environ.get("EESEG_GROUP_WGRAD", "1") == "1"
+        # every ReLU layer's forward can leave the 1-bit mask (1/16 of a tensor pass) so that its backward reads it instead of recomputing
+        # the sign from the conv output and (scale, shift)
+        # (EESEG_BN_MASK_ALL: 0 = residual layers only, the round-2 form; 1 = always; 2 = default: where the backward is two passes)
+        self.bn_mask_all = int(__import__("os").environ.get("EESEG_BN_MASK_ALL", "2"))
         self._wgrad_queue = []
         self._deferred = None
         self.comm = None                     # comm.DataParallelComm: RCCL through libeeseg (parallel.init_data_parallel)
@@ -462,7 +466,9 @@ def conv_bn_fwd(cfg, x, conv, bn, relu, residual=None, out=None, x_is_col=False,
     bn._pending_batches += 1
     # backward recomputes the ReLU mask from c*scale+shift when there is no residual input (saves streaming y
     # again); with a residual the forward leaves a byte mask (1 bit per element) as the mask source
-    if residual is not None and relu:
+    # ... and, round 4, for every ReLU layer whose backward will be the two-pass form (tensors too large for the one-launch
+    # BatchNorm backward): reading 1 bit per element beats recomputing the sign in both passes (B=32: -0.5 ms per step)
+    if relu and (residual is not None or cfg.bn_mask_all == 1 or (cfg.bn_mask_all == 2 and c.is_cuda and not K.bn_bwd_coop_ok(c))):
         y, mask = K.bn_apply(c, ss, residual=residual, relu=True, out=out, want_mask=True)
         return y, (x, c, mask, mi, count, relu, ss)
     y = K.bn_apply(c, ss, residual=residual, relu=relu, out=out)
