@@ -1939,7 +1939,9 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int cl = wave * 64 + i * 32 + 8 * gq + 4 * fh;
-                    char* d = slot + fr * WS_ROWB + ((((cl >> 3) ^ fx) << 4) | ((cl & 4) << 1));
+                    // (the 8-byte half of the chunk is flipped for pixels 8-15 of every 16: a 16-lane store group - pixels fr .. fr + 15 of
+                    // one accumulator half - then covers all 32 banks instead of the even 8-byte slots of 16 chunks twice; round 4)
+                    char* d = slot + fr * WS_ROWB + ((((cl >> 3) ^ fx) << 4) | ((((cl >> 2) ^ (fr >> 3)) & 1) << 3));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x4*>(d + j * 32 * WS_ROWB) = packed[j][i][gq];
                 }
@@ -1972,7 +1974,8 @@ __global__ __launch_bounds__(256, 2) void conv_pws_kernel(ConvP p) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = r0 + 8 * (ps * 4 + it);
-                    rq[it] = *reinterpret_cast<const i32x4*>(slot + row * WS_ROWB + ((c ^ (row & 15)) << 4));
+                    const i32x4 q = *reinterpret_cast<const i32x4*>(slot + row * WS_ROWB + ((c ^ (row & 15)) << 4));
+                    rq[it] = ((row >> 3) & 1) ? i32x4{q[2], q[3], q[0], q[1]} : q;
                 }
                 if (ps == 1) {
                     WS_LDS_BARRIER();                             // staging consumed by every thread: the slot is free
